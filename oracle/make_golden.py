@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE: regenerate tests/golden/ from the genuine reference.
+
+Runs oracle/_ref/Force2Vec (built from /root/reference by oracle/build_ref.sh; neither
+exists on the GPU box, which only consumes the committed fixtures) on the reference's own
+bundled datasets and stores, per case, the md5 of the .embd text it wrote and -- for the
+small cases -- the text itself (gzip).  Also stores the sigmoid table exactly as this
+host's compiled reference computes it (see f2v_oracle.c:orc_sm_table_as_compiled) so that
+option 6/7 goldens can be reproduced on hosts whose rcpps differs, and the first values of
+libc rand() after srand(1).
+
+Usage: python oracle/make_golden.py      (from the repo root, in the build container)
+"""
+import ctypes
+import gzip
+import hashlib
+import json
+import os
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path = [q for q in sys.path if os.path.abspath(q or ".") != os.path.join(ROOT, "oracle")]
+sys.path.insert(0, ROOT)
+from oracle import oracle as O  # noqa: E402
+
+REF_INPUT = "/root/reference/datasets/input"
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+# (graph, option, iters, batch, dim, bs, keep_text)
+CASES = [
+    ("karate.mtx", 5, 1, 16, 16, 0, True),
+    ("karate.mtx", 5, 10, 16, 16, 0, True),
+    ("karate.mtx", 5, 10, 7, 16, 1, True),
+    ("karate.mtx", 5, 3, 64, 128, 0, True),      # batch > N: a single minibatch
+    ("karate.mtx", 6, 10, 16, 16, 0, True),
+    ("karate.mtx", 6, 10, 7, 32, 1, True),
+    ("karate.mtx", 7, 10, 16, 16, 0, True),
+    ("karate.mtx", 7, 5, 5, 128, 0, True),
+    ("cora.mtx", 5, 1, 256, 16, 0, False),
+    ("cora.mtx", 5, 10, 256, 16, 0, True),
+    ("cora.mtx", 5, 1200, 256, 16, 0, False),    # BASELINE config 1
+    ("cora.mtx", 5, 1, 256, 128, 0, False),
+    ("cora.mtx", 5, 10, 256, 128, 0, True),      # BASELINE config 2 (short)
+    ("cora.mtx", 5, 100, 256, 128, 0, False),
+    ("cora.mtx", 5, 5, 256, 64, 1, False),
+    ("cora.mtx", 5, 10, 384, 128, 0, False),     # CLI default batch
+    ("cora.mtx", 6, 10, 256, 128, 0, True),
+    ("cora.mtx", 6, 300, 256, 128, 0, False),
+    ("cora.mtx", 6, 5, 256, 64, 1, False),
+    ("cora.mtx", 7, 10, 256, 128, 0, True),
+    ("cora.mtx", 7, 300, 256, 128, 0, False),
+    ("citeseer.mtx", 5, 5, 500, 32, 0, False),
+    ("citeseer.mtx", 6, 5, 500, 32, 0, False),
+]
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    manifest = {"generator": "oracle/make_golden.py", "reference_flags": "-g -fomit-frame-pointer -ffast-math -fopenmp -O3 -std=c++11 -DCPP",
+                "compiler": os.popen("g++ --version").readline().strip(), "cases": []}
+    for g, option, iters, batch, dim, bs, keep in CASES:
+        mtx = os.path.join(REF_INPUT, g)
+        with tempfile.TemporaryDirectory() as td:
+            path, _ = O.run_reference(mtx, td, option, iters, batch, dim, bs=bs, threads=1)
+            txt = open(path, "rb").read()
+            name = "%s_opt%d_it%d_B%d_D%d_bs%d" % (g.replace(".mtx", ""), option, iters, batch, dim, bs)
+            entry = {"name": name, "graph": g, "option": option, "iters": iters, "batch": batch, "dim": dim, "bs": bs,
+                     "ns": 5, "lr": 0.02, "md5": hashlib.md5(txt).hexdigest(), "embd_name": os.path.basename(path)}
+            if keep:
+                with gzip.GzipFile(os.path.join(GOLD, name + ".embd.gz"), "wb", mtime=0) as f:
+                    f.write(txt)
+                entry["file"] = name + ".embd.gz"
+            manifest["cases"].append(entry)
+            print(name, entry["md5"])
+    # the graphs themselves are the reference's test data (inputs): keep the two tiny ones
+    for g in ("karate.mtx", "cora.mtx"):
+        shutil.copy(os.path.join(REF_INPUT, g), os.path.join(GOLD, g))
+    shutil.copy(os.path.join(REF_INPUT, "cora.nodes.labels"), os.path.join(GOLD, "cora.nodes.labels"))
+    for g in ("citeseer.mtx",):
+        with open(os.path.join(REF_INPUT, g), "rb") as fi, gzip.GzipFile(os.path.join(GOLD, g + ".gz"), "wb", mtime=0) as fo:
+            fo.write(fi.read())
+    t, ok = O.sm_table_as_compiled()
+    assert ok
+    t.astype("<f4").tofile(os.path.join(GOLD, "sm_table_as_compiled.f32"))
+    manifest["sm_table_as_compiled"] = {"file": "sm_table_as_compiled.f32", "host_cpu": os.popen("grep -m1 'model name' /proc/cpuinfo").read().split(":")[-1].strip()}
+    libc = ctypes.CDLL("libc.so.6")
+    libc.srand(1)
+    manifest["rand_after_srand1"] = [libc.rand() for _ in range(16)]
+    libc.srand(1)
+    for _ in range(1000000):
+        v = libc.rand()
+    manifest["rand_1000000th"] = v
+    with open(os.path.join(GOLD, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
