@@ -1,0 +1,23 @@
+# Builds the MI355X (gfx950) Force2Vec engine: libf2v.so (C ABI, include/f2v.h) and the
+# drop-in CLI bin/Force2Vec.  hipcc cross-compiles without a GPU.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+CSRC = force2vec_amd/csrc
+# -ffp-contract=off: the reference's mul/add pairs are separate roundings (x86-64 without FMA);
+# parity with the oracle depends on it.
+CXXFLAGS = -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result
+HIPFLAGS = --offload-arch=$(ARCH) $(CXXFLAGS)
+LIB = force2vec_amd/libf2v.so
+
+all: $(LIB) bin/Force2Vec
+
+$(LIB): $(CSRC)/f2v_engine.hip $(CSRC)/f2v_kernels.hip.h $(CSRC)/f2v_host.cpp $(CSRC)/f2v_internal.h include/f2v.h
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/f2v_engine.hip $(CSRC)/f2v_host.cpp
+
+bin/Force2Vec: $(CSRC)/cli_main.cpp $(CSRC)/algorithms.hpp include/f2v.h $(LIB)
+	mkdir -p bin
+	$(HIPCC) $(CXXFLAGS) -o $@ $(CSRC)/cli_main.cpp -Lforce2vec_amd -lf2v -Wl,-rpath,'$$ORIGIN/../force2vec_amd'
+
+clean:
+	rm -f $(LIB) bin/Force2Vec
+.PHONY: all clean

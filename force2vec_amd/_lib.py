@@ -1,0 +1,86 @@
+"""ctypes binding of libf2v.so (include/f2v.h).  The library is built in-tree by `make`
+(or __graft_entry__.build()); there is no fallback implementation -- a missing library
+is an ImportError, a missing GPU is F2V_ENODEV from f2v_create."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libf2v.so")
+
+F2V_OK, F2V_EINVAL, F2V_ENODEV, F2V_ENOMEM, F2V_EIO, F2V_ESTATE = 0, -1, -2, -3, -4, -5
+INIT_SYMMETRIC, INIT_UNIT = 0, 1
+
+u32p = C.POINTER(C.c_uint32)
+f32p = C.POINTER(C.c_float)
+
+
+class Stats(C.Structure):
+    _fields_ = [("step_launches", C.c_uint64), ("rows", C.c_uint64), ("nnz", C.c_uint64),
+                ("algorithmic_bytes", C.c_uint64), ("device_seconds", C.c_double),
+                ("hub_rows", C.c_uint64), ("hub_chunks", C.c_uint64)]
+
+
+# every entry point declared in include/f2v.h: name -> (restype, argtypes)
+SIGNATURES = {
+    "f2v_last_error": (C.c_char_p, []),
+    "f2v_version": (C.c_char_p, []),
+    "f2v_create": (C.c_int, [u32p, u32p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]),
+    "f2v_destroy": (C.c_int, [C.c_void_p]),
+    "f2v_srand": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "f2v_init_embeddings": (C.c_int, [C.c_void_p, C.c_int]),
+    "f2v_set_embeddings": (C.c_int, [C.c_void_p, f32p]),
+    "f2v_get_embeddings": (C.c_int, [C.c_void_p, f32p]),
+    "f2v_set_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "f2v_get_param": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
+    "f2v_train": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_int, C.POINTER(C.c_double)]),
+    "f2v_minibatch_step": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u32p, C.c_uint32, C.c_uint32, C.c_float, C.c_int]),
+    "f2v_flush": (C.c_int, [C.c_void_p]),
+    "f2v_set_walks": (C.c_int, [C.c_void_p, u32p]),
+    "f2v_generate_walks": (C.c_int, [C.c_void_p, u32p]),
+    "f2v_rand_index": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, u32p]),
+    "f2v_stage_device_ptr": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), u32p]),
+    "f2v_stage_read": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, f32p]),
+    "f2v_stage_write": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, f32p]),
+    "f2v_stage_reserve": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "f2v_embeddings_device_ptr": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "f2v_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "f2v_synchronize": (C.c_int, [C.c_void_p]),
+    "f2v_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "f2v_read_mtx": (C.c_int, [C.c_char_p, u32p, C.POINTER(C.c_uint64), C.POINTER(u32p), C.POINTER(u32p)]),
+    "f2v_free": (None, [C.c_void_p]),
+    "f2v_write_embd": (C.c_int, [C.c_char_p, f32p, C.c_uint32, C.c_uint32]),
+    "f2v_output_name": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p, C.c_size_t]),
+    "f2v_rng_create": (C.c_void_p, [C.c_uint32]),
+    "f2v_rng_destroy": (None, [C.c_void_p]),
+    "f2v_rng_next": (C.c_int, [C.c_void_p]),
+    "f2v_sm_table": (C.c_int, [f32p]),
+    "f2v_test_wave_reduce": (C.c_int, [C.c_int, f32p, C.c_uint32, C.c_uint32, f32p]),
+}
+
+_lib = None
+
+
+class F2VError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libf2v error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: build it with `make` (hipcc --offload-arch=gfx950); "
+                              "force2vec_amd has no fallback implementation" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != F2V_OK:
+        raise F2VError(rc, lib().f2v_last_error().decode(errors="replace"))

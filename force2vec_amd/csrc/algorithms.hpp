@@ -1,0 +1,100 @@
+// algorithms.hpp -- host-side mirror of the reference's `class algorithms`
+// (sample/algorithms.h:51-137) over the C ABI of libf2v: same constructor arguments, same
+// method names and argument meaning for the options 5-11 entry points, same side effects
+// (the "... Wall time required:" line, the .embd file, result = {seconds}).  The embedding
+// matrix lives in HBM; nothing here computes forces.
+#ifndef F2V_ALGORITHMS_HPP_
+#define F2V_ALGORITHMS_HPP_
+#include <chrono>
+#include <cstdint>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "f2v.h"
+
+#define VALUETYPE float
+#define INDEXTYPE unsigned int
+
+namespace f2v_host {
+
+struct CSRGraph {  // CSR<INDEXTYPE, VALUETYPE> of sample/CSR.h:89-96 (values are never read by options 5-11)
+    INDEXTYPE rows = 0;
+    uint64_t nnz = 0;
+    INDEXTYPE *rowptr = nullptr;
+    INDEXTYPE *colids = nullptr;
+    ~CSRGraph() { f2v_free(rowptr); f2v_free(colids); }
+    CSRGraph() = default;
+    CSRGraph(const CSRGraph &) = delete;
+    CSRGraph &operator=(const CSRGraph &) = delete;
+};
+
+// SetInputMatricesAsCSR, sample/commonutility.h:44-54
+inline void SetInputMatricesAsCSR(CSRGraph &A, const std::string &inputfile) {
+    std::cout << "Reading input matrices in text (ascii)... " << std::endl;
+    std::cout << "Input File Directory:" << inputfile << std::endl;
+    if (f2v_read_mtx(inputfile.c_str(), &A.rows, &A.nnz, &A.rowptr, &A.colids) != F2V_OK) throw std::runtime_error(f2v_last_error());
+    std::cout << "Input Matrix: Rows = " << A.rows << ", nnz = " << A.nnz << std::endl;
+}
+
+class algorithms {
+   public:
+    f2v_handle h = nullptr;
+    INDEXTYPE DIM, rows;
+    std::string filename, outputdir;
+    double gpu_train_seconds = 0.0;  // device time of the epoch loop alone
+    f2v_stats stats{};
+
+    algorithms(CSRGraph &A_csr, std::string input, std::string outputd, INDEXTYPE dim, VALUETYPE /*gamma*/, INDEXTYPE /*bsize*/, int device = 0)
+        : DIM(dim), rows(A_csr.rows), filename(input), outputdir(outputd) {
+        if (f2v_create(A_csr.rowptr, A_csr.colids, A_csr.rows, A_csr.nnz, dim, device, &h) != F2V_OK) throw std::runtime_error(f2v_last_error());
+    }
+    ~algorithms() { f2v_destroy(h); }
+    algorithms(const algorithms &) = delete;
+
+    void srand(unsigned seed) { check(f2v_srand(h, seed)); }  // Test/Force2Vec.cpp:126
+
+    // options 5 / 5 -bs 1 / 6 / 6 -bs 1 / 7 (sample/algorithms.h:86-91)
+    std::vector<VALUETYPE> AlgoForce2VecNS(INDEXTYPE IT, INDEXTYPE TH, INDEXTYPE B, INDEXTYPE ns, VALUETYPE lr) { return run(5, 0, IT, B, ns, lr, "Force2Vec Parallel Wall time required:"); }
+    std::vector<VALUETYPE> AlgoForce2VecNSBS(INDEXTYPE IT, INDEXTYPE TH, INDEXTYPE B, INDEXTYPE ns, VALUETYPE lr) { return run(5, 1, IT, B, ns, lr, "Force2Vec Parallel Wall time required (with BS negative samples):"); }
+    std::vector<VALUETYPE> AlgoForce2VecNSRW(INDEXTYPE IT, INDEXTYPE TH, INDEXTYPE B, INDEXTYPE ns, VALUETYPE lr) { return run(6, 0, IT, B, ns, lr, "Force2Vec Parallel Wall time required:"); }
+    std::vector<VALUETYPE> AlgoForce2VecNSRWBS(INDEXTYPE IT, INDEXTYPE TH, INDEXTYPE B, INDEXTYPE ns, VALUETYPE lr) { return run(6, 1, IT, B, ns, lr, "Force2Vec Parallel Wall time required (with BS negative samples):"); }
+    std::vector<VALUETYPE> AlgoForce2VecNSRWEFF(INDEXTYPE IT, INDEXTYPE TH, INDEXTYPE B, INDEXTYPE ns, VALUETYPE lr) { return run(7, 0, IT, B, ns, lr, "Force2VecWNSEFF Parallel Wall time required:"); }
+    // the AVX512 entry points (sample/algorithms.h:93-102): same maths on the GPU, hub rows load-balanced
+    std::vector<VALUETYPE> AlgoForce2VecNS_SREAL_D128_AVXZ(INDEXTYPE IT, INDEXTYPE TH, INDEXTYPE B, INDEXTYPE ns, VALUETYPE lr) { return run(8, 0, IT, B, ns, lr, "Force2Vec Parallel Wall time required:"); }
+    std::vector<VALUETYPE> AlgoForce2VecNSRW_SREAL_D128_AVXZ(INDEXTYPE IT, INDEXTYPE TH, INDEXTYPE B, INDEXTYPE ns, VALUETYPE lr) { return run(9, 0, IT, B, ns, lr, "Force2Vec Parallel Wall time required:"); }
+    std::vector<VALUETYPE> AlgoForce2VecNSRWEFF_SREAL_D128_AVXZ(INDEXTYPE IT, INDEXTYPE TH, INDEXTYPE B, INDEXTYPE ns, VALUETYPE lr) { return run(10, 0, IT, B, ns, lr, "Force2VecWNSEFF Parallel Wall time required:"); }
+    std::vector<VALUETYPE> AlgoForce2VecNSLB_SREAL_D128_AVXZ(INDEXTYPE IT, INDEXTYPE TH, INDEXTYPE B, INDEXTYPE ns, VALUETYPE lr) { return run(11, 0, IT, B, ns, lr, "Force2Vec Parallel Wall time required:"); }
+
+    // writeToFile, sample/algorithms.h:118-136 (file name rule in f2v_output_name)
+    void writeToFile(int option, int bs, INDEXTYPE B, INDEXTYPE IT, INDEXTYPE ns) {
+        char name[4096];
+        check(f2v_output_name(filename.c_str(), outputdir.c_str(), option, bs, B, DIM, IT, ns, name, sizeof name));
+        std::cout << "Creating output file in following directory:" << name << std::endl;
+        std::vector<float> x((size_t)rows * DIM);
+        check(f2v_get_embeddings(h, x.data()));
+        check(f2v_write_embd(name, x.data(), rows, DIM));
+    }
+
+   private:
+    static void check(int rc) {
+        if (rc != F2V_OK) throw std::runtime_error(f2v_last_error());
+    }
+    std::vector<VALUETYPE> run(int option, int bs, INDEXTYPE IT, INDEXTYPE B, INDEXTYPE ns, VALUETYPE lr, const char *msg) {
+        // the reference's timer spans randInit + the epoch loop (algorithms.cpp:557-558, 647)
+        auto t0 = std::chrono::steady_clock::now();
+        const int math = (option == 5 || option == 8 || option == 11) ? 5 : 6;
+        check(f2v_init_embeddings(h, math == 5 ? F2V_INIT_SYMMETRIC : F2V_INIT_UNIT));
+        check(f2v_train(h, option, IT, B, ns, lr, bs, &gpu_train_seconds));
+        auto t1 = std::chrono::steady_clock::now();
+        const double sec = std::chrono::duration<double>(t1 - t0).count();
+        std::cout << msg << sec << " seconds" << std::endl;
+        f2v_get_stats(h, &stats);
+        writeToFile(option, bs, B, IT, ns);
+        return std::vector<VALUETYPE>{(VALUETYPE)sec};
+    }
+};
+
+}  // namespace f2v_host
+#endif

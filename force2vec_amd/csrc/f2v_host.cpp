@@ -1,0 +1,221 @@
+// f2v_host.cpp -- host-side pieces of the drop-in boundary: the libc rand() stream the
+// reference draws from, MatrixMarket ingest into CSR, the .embd writer and file naming,
+// the sigmoid table.  No device code here; see f2v_engine.hip for the HBM side.
+#include <algorithm>
+#include <cerrno>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "f2v.h"
+#include "f2v_internal.h"
+
+namespace f2v {
+
+static thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// ---- libc rand(): glibc's TYPE_3 additive-feedback generator -------------------------------
+// r[i] = r[i-3] + r[i-31] (mod 2^32), output = r[i] >> 1; srandom_r seeds r[0..30] with the
+// Lehmer sequence 16807*x mod (2^31-1) and discards the first 310 outputs.  Restated so that
+// results do not depend on the platform libc; the reference seeds with srand(1)
+// (Test/Force2Vec.cpp:126) and draws with rand() (sample/algorithms.cpp:41,50,56).
+void Rand::seed(uint32_t s) {
+    if (s == 0) s = 1;
+    r[0] = (int32_t)s;
+    for (int i = 1; i < 31; i++) {
+        long hi = r[i - 1] / 127773, lo = r[i - 1] % 127773;
+        long w = 16807 * lo - 2836 * hi;
+        if (w < 0) w += 2147483647;
+        r[i] = (int32_t)w;
+    }
+    f = 3;
+    b = 0;
+    for (int i = 0; i < 310; i++) next();
+}
+
+void init_embeddings_host(Rand &g, float *x, size_t total, int kind) {
+    // double arithmetic narrowed on store, as `-1.0 + 2.0 * rand()/(RAND_MAX+1.0)` compiles
+    if (kind == F2V_INIT_SYMMETRIC)
+        for (size_t k = 0; k < total; k++) x[k] = (float)(-1.0 + 2.0 * (double)g.next() / 2147483648.0);
+    else
+        for (size_t k = 0; k < total; k++) x[k] = (float)((double)g.next() / 2147483648.0);
+}
+
+void sm_table_host(float *t) {
+    // init_SM_TABLE (sample/algorithms.cpp:757-764): float x, float exp, double reciprocal
+    for (int i = 0; i < kSmTableSize; i++) {
+        float x = (float)(2.0 * kSmBound * i / kSmTableSize - kSmBound);
+        t[i] = (float)(1.0 / (double)(1.0f + expf(-x)));
+    }
+}
+
+}  // namespace f2v
+
+using namespace f2v;
+
+extern "C" {
+
+const char *f2v_last_error(void) { return g_err; }
+const char *f2v_version(void) { return "f2v-mi355x 0.1 (gfx950)"; }
+
+f2v_rng *f2v_rng_create(uint32_t seed) {
+    Rand *g = new Rand();
+    g->seed(seed);
+    return reinterpret_cast<f2v_rng *>(g);
+}
+void f2v_rng_destroy(f2v_rng *g) { delete reinterpret_cast<Rand *>(g); }
+int f2v_rng_next(f2v_rng *g) { return reinterpret_cast<Rand *>(g)->next(); }
+
+int f2v_sm_table(float *t) {
+    if (!t) return fail(F2V_EINVAL, "f2v_sm_table: null output");
+    sm_table_host(t);
+    return F2V_OK;
+}
+
+void f2v_free(void *p) { free(p); }
+
+// MatrixMarket coordinate text -> CSR with the reference's semantics (sample/IO.h:59-156):
+//  * leading lines starting with '%' are header/comments; the word "symmetric" in any of
+//    them mirrors every off-diagonal entry and DROPS diagonal entries (IO.h:122-134);
+//    a general matrix keeps its diagonal;
+//  * entries are "row col [value]" (1-based); the value is ignored by options 5-11;
+//  * duplicates are kept; column ids end up ascending inside each row
+//    (CSC per-column sort CSC.h:173-186, then transpose CSR.h:172-182).
+int f2v_read_mtx(const char *path, uint32_t *n_out, uint64_t *nnz_out, uint32_t **rowptr_out, uint32_t **colids_out) {
+    if (!path || !n_out || !nnz_out || !rowptr_out || !colids_out) return fail(F2V_EINVAL, "f2v_read_mtx: null argument");
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return fail(F2V_EIO, "f2v_read_mtx: cannot open %s: %s", path, strerror(errno));
+    // slurp: the parse below is a single pass over memory (fast path for 10^8-edge files)
+    fseek(fp, 0, SEEK_END);
+    long fsz = ftell(fp);
+    fseek(fp, 0, SEEK_SET);
+    std::vector<char> buf((size_t)fsz + 1);
+    size_t got = fread(buf.data(), 1, (size_t)fsz, fp);
+    fclose(fp);
+    buf[got] = 0;
+    const char *p = buf.data(), *end = buf.data() + got;
+    static const char kSym[] = "symmetric";
+    bool symmetric = false;
+    while (p < end && *p == '%') {
+        const char *eol = (const char *)memchr(p, '\n', (size_t)(end - p));
+        if (!eol) eol = end;
+        if (std::search(p, eol, kSym, kSym + 9) != eol) symmetric = true;
+        p = eol < end ? eol + 1 : end;
+    }
+    auto parse_uint = [&](uint64_t &v) -> bool {
+        while (p < end && (*p == ' ' || *p == '\t' || *p == '\r')) p++;
+        if (p >= end || *p < '0' || *p > '9') return false;
+        uint64_t x = 0;
+        while (p < end && *p >= '0' && *p <= '9') x = x * 10 + (uint64_t)(*p++ - '0');
+        v = x;
+        return true;
+    };
+    auto skip_line = [&]() {
+        const char *eol = (const char *)memchr(p, '\n', (size_t)(end - p));
+        p = eol ? eol + 1 : end;
+    };
+    uint64_t m = 0, n = 0, nz = 0;
+    if (!parse_uint(m) || !parse_uint(n) || !parse_uint(nz)) return fail(F2V_EIO, "f2v_read_mtx: %s: bad size line", path);
+    skip_line();
+    if (m >= 0xFFFFFFFFull) return fail(F2V_EINVAL, "f2v_read_mtx: %llu rows exceed 32-bit vertex ids", (unsigned long long)m);
+    std::vector<uint32_t> rows, cols;
+    rows.reserve((size_t)nz * (symmetric ? 2 : 1));
+    cols.reserve((size_t)nz * (symmetric ? 2 : 1));
+    for (uint64_t k = 0; k < nz && p < end; k++) {
+        uint64_t r, c;
+        if (!parse_uint(r) || !parse_uint(c)) { skip_line(); continue; }
+        skip_line();
+        if (r == 0 || c == 0 || r > m || c > m) return fail(F2V_EIO, "f2v_read_mtx: %s: entry %llu out of range", path, (unsigned long long)k);
+        uint32_t ri = (uint32_t)(r - 1), ci = (uint32_t)(c - 1);
+        if (symmetric) {
+            if (ri == ci) continue;
+            rows.push_back(ri); cols.push_back(ci);
+            rows.push_back(ci); cols.push_back(ri);
+        } else {
+            rows.push_back(ri); cols.push_back(ci);
+        }
+    }
+    const size_t cnt = rows.size();
+    uint32_t *rowptr = (uint32_t *)calloc((size_t)m + 1, sizeof(uint32_t));
+    uint32_t *colids = (uint32_t *)malloc((cnt ? cnt : 1) * sizeof(uint32_t));
+    if (!rowptr || !colids) { free(rowptr); free(colids); return fail(F2V_ENOMEM, "f2v_read_mtx: out of memory"); }
+    if (cnt >= 0xFFFFFFFFull) { free(rowptr); free(colids); return fail(F2V_EINVAL, "f2v_read_mtx: nnz exceeds 32-bit row pointers"); }
+    // two stable counting passes: by column, then by row  =>  (row, col) ascending, duplicates kept
+    const size_t ncols = (size_t)m;  // every column id is a vertex id (< rows), checked above
+    std::vector<uint32_t> cnt_c(ncols + 1, 0), order(cnt);
+    for (size_t k = 0; k < cnt; k++) cnt_c[cols[k] + 1]++;
+    for (size_t c = 0; c < ncols; c++) cnt_c[c + 1] += cnt_c[c];
+    for (size_t k = 0; k < cnt; k++) order[cnt_c[cols[k]]++] = (uint32_t)k;
+    for (size_t k = 0; k < cnt; k++) rowptr[rows[k] + 1]++;
+    for (size_t i = 0; i < m; i++) rowptr[i + 1] += rowptr[i];
+    std::vector<uint32_t> fill(rowptr, rowptr + m);
+    for (size_t q = 0; q < cnt; q++) {
+        uint32_t k = order[q];
+        colids[fill[rows[k]]++] = cols[k];
+    }
+    *n_out = (uint32_t)m;
+    *nnz_out = cnt;
+    *rowptr_out = rowptr;
+    *colids_out = colids;
+    return F2V_OK;
+}
+
+// writeToFile (sample/algorithms.h:118-136): ostream << float is "%g" with 6 significant digits.
+int f2v_write_embd(const char *path, const float *x, uint32_t n, uint32_t dim) {
+    if (!path || !x) return fail(F2V_EINVAL, "f2v_write_embd: null argument");
+    FILE *fp = fopen(path, "wb");
+    if (!fp) return fail(F2V_EIO, "f2v_write_embd: cannot open %s: %s", path, strerror(errno));
+    std::vector<char> line((size_t)dim * 16 + 32);
+    fprintf(fp, "%u %u\n", n, dim);
+    for (uint32_t i = 0; i < n; i++) {
+        char *q = line.data();
+        q += sprintf(q, "%u ", i + 1);
+        const float *row = x + (size_t)i * dim;
+        for (uint32_t d = 0; d < dim; d++) q += sprintf(q, "%g ", (double)row[d]);
+        *q++ = '\n';
+        if (fwrite(line.data(), 1, (size_t)(q - line.data()), fp) != (size_t)(q - line.data())) {
+            fclose(fp);
+            return fail(F2V_EIO, "f2v_write_embd: short write to %s", path);
+        }
+    }
+    if (fclose(fp) != 0) return fail(F2V_EIO, "f2v_write_embd: close failed for %s", path);
+    return F2V_OK;
+}
+
+int f2v_output_name(const char *input, const char *outdir, int option, int bs_mode, uint32_t batch, uint32_t dim,
+                    uint32_t iters, uint32_t ns, char *out, size_t out_len) {
+    if (!input || !outdir || !out) return fail(F2V_EINVAL, "f2v_output_name: null argument");
+    // basename = last '/'-separated token (algorithms.h:119-121)
+    std::string in(input), base;
+    size_t pos = in.find_last_of('/');
+    base = pos == std::string::npos ? in : in.substr(pos + 1);
+    const char *tag;
+    switch (option) {
+        case 5: tag = "F2VNS"; break;             // algorithms.cpp:650 (and :752 for -bs 1)
+        case 6: tag = "F2VWNS"; break;            // :930 (:1059)
+        case 7: tag = "F2VWNSF"; break;           // :1201
+        case 8: tag = "F2VNS_AVXZ"; break;        // :1635
+        case 9: tag = dim == 64 ? "F2VWNSLB64_AVXZ" : "F2VWNS_AVXZ"; break;        // :3235 / :2047
+        case 10: tag = dim == 64 ? "F2VWEFFNS_AVXZ64" : "F2VWEFFNS_AVXZ"; break;   // :4047 / :2409
+        case 11: tag = dim == 64 ? "F2VNSLB_AVXZ64" : "F2VNSLB_AVXZ"; break;       // :3681 / :2860
+        default: return fail(F2V_EINVAL, "f2v_output_name: option %d is outside 5..11", option);
+    }
+    (void)bs_mode;
+    int w = snprintf(out, out_len, "%s%s%s%uD%uIT%uNS%u.embd", outdir, base.c_str(), tag, batch, dim, iters, ns);
+    if (w < 0 || (size_t)w >= out_len) return fail(F2V_EINVAL, "f2v_output_name: buffer too small");
+    return F2V_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,36 @@
+// f2v_internal.h -- shared between the host-side boundary code and the HBM engine.
+#ifndef F2V_INTERNAL_H_
+#define F2V_INTERNAL_H_
+#include <cstddef>
+#include <cstdint>
+
+namespace f2v {
+
+constexpr int kSmTableSize = 2048;   // SM_TABLE_SIZE, sample/algorithms.h:43
+constexpr double kSmBound = 6.0;     // SM_BOUND, sample/algorithms.h:44
+constexpr int kWalkLength = 5;       // WALKLENGTH, sample/algorithms.cpp:1073
+constexpr float kMaxBound = 5.0f;    // MAXBOUND, sample/algorithms.h:41
+
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// glibc rand() stream (TYPE_3 additive feedback), see f2v_host.cpp
+struct Rand {
+    int32_t r[31];
+    int f, b;
+    void seed(uint32_t s);
+    inline int next() {
+        uint32_t v = (uint32_t)r[f] + (uint32_t)r[b];
+        r[f] = (int32_t)v;
+        if (++f >= 31) f = 0;
+        if (++b >= 31) b = 0;
+        return (int)(v >> 1);
+    }
+    // randIndex(max,min), sample/algorithms.cpp:55-58
+    inline uint32_t index(uint32_t max_num, uint32_t min_num) { return ((uint32_t)next() % (max_num - min_num)) + min_num; }
+};
+
+void init_embeddings_host(Rand &g, float *x, size_t total, int kind);
+void sm_table_host(float *t);
+
+}  // namespace f2v
+#endif

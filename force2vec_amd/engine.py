@@ -1,0 +1,209 @@
+"""Host-side mirror of the reference's operator interface over libf2v (include/f2v.h).
+
+`Engine` is the thin handle wrapper; `algorithms` mirrors `class algorithms` of
+sample/algorithms.h:51-137 -- same constructor meaning, same AlgoForce2Vec* method names and
+(ITERATIONS, NUMOFTHREADS, BATCHSIZE, ns, lr) arguments, result [seconds], side effect = the
+.embd file -- so the parity tests read like a user of the reference.  All force arithmetic
+runs in the HIP kernels; nothing here (or anywhere in this package) computes on the CPU."""
+import ctypes as C
+import os
+import time
+
+import numpy as np
+
+from . import _lib
+from ._lib import INIT_SYMMETRIC, INIT_UNIT, check
+
+
+def _u32(a):
+    return a.ctypes.data_as(_lib.u32p)
+
+
+def _f32(a):
+    return a.ctypes.data_as(_lib.f32p)
+
+
+class Engine:
+    """One HBM-resident graph + embedding matrix on one MI355X."""
+
+    def __init__(self, rowptr, colids, dim, device=0):
+        self._L = _lib.lib()
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.uint32)
+        colids = np.ascontiguousarray(colids, dtype=np.uint32)
+        self.n = len(rowptr) - 1
+        self.nnz = int(rowptr[-1])
+        self.dim = int(dim)
+        self.rowptr, self.colids = rowptr, colids
+        h = C.c_void_p()
+        check(self._L.f2v_create(_u32(rowptr), _u32(colids), self.n, self.nnz, self.dim, device, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.f2v_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # -- rand() stream / embeddings ---------------------------------------------------------
+    def srand(self, seed=1):
+        check(self._L.f2v_srand(self._h, seed))
+
+    def init_embeddings(self, kind):
+        check(self._L.f2v_init_embeddings(self._h, kind))
+
+    def set_embeddings(self, X):
+        X = np.ascontiguousarray(X, dtype=np.float32)
+        assert X.shape == (self.n, self.dim)
+        check(self._L.f2v_set_embeddings(self._h, _f32(X)))
+
+    def get_embeddings(self):
+        X = np.empty((self.n, self.dim), dtype=np.float32)
+        check(self._L.f2v_get_embeddings(self._h, _f32(X)))
+        return X
+
+    def rand_index(self, max_num, min_num=0):
+        out = C.c_uint32()
+        check(self._L.f2v_rand_index(self._h, max_num, min_num, C.byref(out)))
+        return out.value
+
+    def set_param(self, name, value):
+        check(self._L.f2v_set_param(self._h, name.encode(), int(value)))
+
+    def get_param(self, name):
+        v = C.c_int64()
+        check(self._L.f2v_get_param(self._h, name.encode(), C.byref(v)))
+        return v.value
+
+    # -- training -----------------------------------------------------------------------------
+    def train(self, option, iters, batch, ns=5, lr=0.02, bs_mode=0):
+        """-> device seconds of the epoch loop."""
+        sec = C.c_double()
+        check(self._L.f2v_train(self._h, option, iters, batch, ns, lr, bs_mode, C.byref(sec)))
+        return sec.value
+
+    def minibatch_step(self, option, batch_lo, batch_hi, sample_ids, ns, lr, bs_mode=0, row_lo=None, row_hi=None):
+        ids = np.ascontiguousarray(sample_ids, dtype=np.uint32)
+        check(self._L.f2v_minibatch_step(self._h, option, batch_lo, batch_hi,
+                                         batch_lo if row_lo is None else row_lo, batch_hi if row_hi is None else row_hi,
+                                         _u32(ids), len(ids), ns, lr, bs_mode))
+
+    def flush(self):
+        check(self._L.f2v_flush(self._h))
+
+    def synchronize(self):
+        check(self._L.f2v_synchronize(self._h))
+
+    def set_walks(self, walks):
+        w = np.ascontiguousarray(walks, dtype=np.uint32)
+        assert w.size == 5 * self.n
+        check(self._L.f2v_set_walks(self._h, _u32(w)))
+
+    def generate_walks(self):
+        w = np.empty(5 * self.n, dtype=np.uint32)
+        check(self._L.f2v_generate_walks(self._h, _u32(w)))
+        return w
+
+    def stage_reserve(self, rows):
+        check(self._L.f2v_stage_reserve(self._h, rows))
+
+    def stage_read(self, row_lo, row_hi):
+        out = np.empty((row_hi - row_lo, self.dim), dtype=np.float32)
+        check(self._L.f2v_stage_read(self._h, row_lo, row_hi, _f32(out)))
+        return out
+
+    def stage_write(self, row_lo, row_hi, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        assert rows.shape == (row_hi - row_lo, self.dim)
+        check(self._L.f2v_stage_write(self._h, row_lo, row_hi, _f32(rows)))
+
+    def stage_device_ptr(self):
+        p = C.c_uint64()
+        cap = C.c_uint32()
+        check(self._L.f2v_stage_device_ptr(self._h, C.byref(p), C.byref(cap)))
+        return p.value, cap.value
+
+    def stream(self):
+        s = C.c_uint64()
+        check(self._L.f2v_stream(self._h, C.byref(s)))
+        return s.value
+
+    def stats(self):
+        s = _lib.Stats()
+        check(self._L.f2v_get_stats(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in s._fields_}
+
+
+def write_embd(path, X):
+    X = np.ascontiguousarray(X, dtype=np.float32)
+    check(_lib.lib().f2v_write_embd(str(path).encode(), _f32(X), X.shape[0], X.shape[1]))
+
+
+def output_name(input_path, outdir, option, bs_mode, batch, dim, iters, ns):
+    buf = C.create_string_buffer(4096)
+    check(_lib.lib().f2v_output_name(str(input_path).encode(), str(outdir).encode(), option, bs_mode, batch, dim, iters, ns, buf, len(buf)))
+    return buf.value.decode()
+
+
+def sm_table():
+    t = np.empty(2048, dtype=np.float32)
+    check(_lib.lib().f2v_sm_table(_f32(t)))
+    return t
+
+
+class algorithms:
+    """Mirror of `class algorithms` (sample/algorithms.h:51-137) on the GPU engine."""
+
+    def __init__(self, graph, input_path="", outputdir="", dim=128, gamma=1.0, bsize=384, device=0):
+        rowptr, colids = graph
+        self.engine = Engine(rowptr, colids, dim, device)
+        self.DIM = dim
+        self.filename = input_path
+        self.outputdir = outputdir
+        self.gpu_train_seconds = 0.0
+        self.nCoordinates = None  # filled after a run (host copy of the HBM matrix)
+
+    def srand(self, seed=1):  # Test/Force2Vec.cpp:126
+        self.engine.srand(seed)
+
+    def _run(self, option, bs, ITER, BATCH, ns, lr, write=True):
+        t0 = time.perf_counter()
+        self.engine.init_embeddings(INIT_SYMMETRIC if option in (5, 8, 11) else INIT_UNIT)
+        self.gpu_train_seconds = self.engine.train(option, ITER, BATCH, ns, lr, bs)
+        sec = time.perf_counter() - t0
+        self.nCoordinates = self.engine.get_embeddings()
+        if write and self.filename:
+            self.writeToFile(output_name(self.filename, self.outputdir, option, bs, BATCH, self.DIM, ITER, ns))
+        return [sec]
+
+    def AlgoForce2VecNS(self, ITERATIONS, NUMOFTHREADS, BATCHSIZE, ns, lr):
+        return self._run(5, 0, ITERATIONS, BATCHSIZE, ns, lr)
+
+    def AlgoForce2VecNSBS(self, ITERATIONS, NUMOFTHREADS, BATCHSIZE, ns, lr):
+        return self._run(5, 1, ITERATIONS, BATCHSIZE, ns, lr)
+
+    def AlgoForce2VecNSRW(self, ITERATIONS, NUMOFTHREADS, BATCHSIZE, ns, lr):
+        return self._run(6, 0, ITERATIONS, BATCHSIZE, ns, lr)
+
+    def AlgoForce2VecNSRWBS(self, ITERATIONS, NUMOFTHREADS, BATCHSIZE, ns, lr):
+        return self._run(6, 1, ITERATIONS, BATCHSIZE, ns, lr)
+
+    def AlgoForce2VecNSRWEFF(self, ITERATIONS, NUMOFTHREADS, BATCHSIZE, ns, lr):
+        return self._run(7, 0, ITERATIONS, BATCHSIZE, ns, lr)
+
+    def AlgoForce2VecNS_SREAL_D128_AVXZ(self, ITERATIONS, NUMOFTHREADS, BATCHSIZE, ns, lr):
+        return self._run(8, 0, ITERATIONS, BATCHSIZE, ns, lr)
+
+    def AlgoForce2VecNSRW_SREAL_D128_AVXZ(self, ITERATIONS, NUMOFTHREADS, BATCHSIZE, ns, lr):
+        return self._run(9, 0, ITERATIONS, BATCHSIZE, ns, lr)
+
+    def AlgoForce2VecNSRWEFF_SREAL_D128_AVXZ(self, ITERATIONS, NUMOFTHREADS, BATCHSIZE, ns, lr):
+        return self._run(10, 0, ITERATIONS, BATCHSIZE, ns, lr)
+
+    def AlgoForce2VecNSLB_SREAL_D128_AVXZ(self, ITERATIONS, NUMOFTHREADS, BATCHSIZE, ns, lr):
+        return self._run(11, 0, ITERATIONS, BATCHSIZE, ns, lr)
+
+    def writeToFile(self, path):
+        print("Creating output file in following directory:" + path)
+        write_embd(path, self.nCoordinates)
+        self.last_output = path

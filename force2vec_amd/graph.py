@@ -1,0 +1,86 @@
+"""Graph inputs of the hot path: MatrixMarket ingest (through libf2v's reader, which keeps
+the reference's ReadASCII/CSC/CSR semantics) and the synthetic power-law (RMAT) generator
+BASELINE.md section 3 prescribes for the roofline configs."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def read_mtx(path):
+    """-> (rowptr u32[n+1], colids u32[nnz]) as SetInputMatricesAsCSR builds them (sample/commonutility.h:44-54)."""
+    L = _lib.lib()
+    n = C.c_uint32()
+    nnz = C.c_uint64()
+    rp = _lib.u32p()
+    ci = _lib.u32p()
+    _lib.check(L.f2v_read_mtx(str(path).encode(), C.byref(n), C.byref(nnz), C.byref(rp), C.byref(ci)))
+    try:
+        rowptr = np.ctypeslib.as_array(rp, shape=(n.value + 1,)).copy()
+        colids = np.ctypeslib.as_array(ci, shape=(max(nnz.value, 1),)).copy()[: nnz.value]
+    finally:
+        L.f2v_free(rp)
+        L.f2v_free(ci)
+    return rowptr, colids
+
+
+def csr_from_undirected_edges(n, src, dst):
+    """Symmetric CSR (both directions, ascending colids) from an undirected edge list without self-loops."""
+    r = np.concatenate([src, dst]).astype(np.int64)
+    c = np.concatenate([dst, src]).astype(np.int64)
+    key = r * n + c
+    key.sort(kind="stable")
+    rows = (key // n).astype(np.int64)
+    colids = (key % n).astype(np.uint32)
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(rowptr, rows + 1, 1) if len(rows) < 1 << 16 else None
+    if len(rows) >= 1 << 16:
+        rowptr[1:] = np.bincount(rows, minlength=n)
+    rowptr = np.cumsum(rowptr)
+    assert rowptr[-1] == len(colids) and rowptr[-1] < 2**32
+    return rowptr.astype(np.uint32), colids
+
+
+def rmat_edges(scale, edge_factor=16, seed=1, a=0.57, b=0.19, c=0.19):
+    """RMAT (a,b,c,d)=(0.57,0.19,0.19,0.05) edge list of 2^scale vertices, vertex ids permuted,
+    self-loops and duplicate undirected pairs removed.  -> (n, src, dst) with src > dst."""
+    rng = np.random.default_rng(seed)
+    n = 1 << scale
+    m = n * edge_factor
+    src = np.zeros(m, dtype=np.int64)
+    dst = np.zeros(m, dtype=np.int64)
+    ab, abc = a + b, a + b + c
+    for _ in range(scale):
+        u = rng.random(m)
+        src = (src << 1) | (u >= ab)
+        dst = (dst << 1) | (((u >= a) & (u < ab)) | (u >= abc))
+    perm = rng.permutation(n)
+    src, dst = perm[src], perm[dst]
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    hi, lo = np.maximum(src, dst), np.minimum(src, dst)
+    key = np.unique(hi * n + lo)
+    return n, (key // n).astype(np.int64), (key % n).astype(np.int64)
+
+
+def rmat_csr(scale, edge_factor=16, seed=1):
+    n, s, d = rmat_edges(scale, edge_factor, seed)
+    return csr_from_undirected_edges(n, s, d)
+
+
+def write_mtx_symmetric(path, n, src, dst):
+    """`pattern symmetric` MatrixMarket file (lower triangle, 1-based), the form the reference's datasets use."""
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate pattern symmetric\n")
+        f.write("%d %d %d\n" % (n, n, len(src)))
+        np.savetxt(f, np.stack([src + 1, dst + 1], axis=1), fmt="%d %d")
+
+
+def edges_from_csr(rowptr, colids):
+    """Lower-triangle edge list (src > dst) of a symmetric CSR, duplicates kept."""
+    n = len(rowptr) - 1
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(rowptr.astype(np.int64)))
+    cols = colids.astype(np.int64)
+    m = rows > cols
+    return rows[m], cols[m]

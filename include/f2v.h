@@ -1,0 +1,151 @@
+/*
+ * f2v.h -- C ABI of libf2v, the MI355X (gfx950) Force2Vec embedding engine.
+ *
+ * Drop-in boundary for the ONE hot path of HipGraph/Force2Vec: the per-minibatch
+ * attraction/repulsion force kernels + SGD row update of tForce2Vec / sForce2Vec /
+ * rForce2Vec (CLI options 5-7, and 8-11 as their load-balanced equivalents).  The
+ * reference has no FFI of its own; each entry point below names the reference interface
+ * it replaces (file:line under the reference tree).  Plain pointers and sizes only.
+ *
+ * Conventions: every function returns 0 on success and a negative F2V_E* code on failure
+ * (f2v_last_error() then holds a message for the calling thread).  The caller owns every
+ * host array it passes in (inputs are copied to HBM); the library owns all device state.
+ * One handle per host thread; no global mutable state besides the per-thread error text.
+ * There is NO CPU fallback: without a usable HIP device f2v_create fails with F2V_ENODEV.
+ */
+#ifndef F2V_H_
+#define F2V_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define F2V_OK 0
+#define F2V_EINVAL (-1)  /* bad argument */
+#define F2V_ENODEV (-2)  /* no usable HIP device / HIP runtime error */
+#define F2V_ENOMEM (-3)
+#define F2V_EIO (-4)
+#define F2V_ESTATE (-5)  /* call order violated (e.g. training before init) */
+
+#define F2V_INIT_SYMMETRIC 0 /* randInitF: U[-1,1)  sample/algorithms.cpp:47-53 (options 5,8,11) */
+#define F2V_INIT_UNIT 1      /* randInit : U[0,1)   sample/algorithms.cpp:38-45 (options 6,7,9,10) */
+
+typedef struct f2v_ctx *f2v_handle;
+
+const char *f2v_last_error(void);
+const char *f2v_version(void);
+
+/* ---- engine life cycle -----------------------------------------------------------------
+ * Replaces `algorithms::algorithms(CSR&, input, outputdir, dim, gamma, batch)`
+ * (sample/algorithms.h:60-70): copies the CSR (rowptr u32[n+1], colids u32[nnz], ascending
+ * inside each row, duplicates kept -- sample/CSR.h:89-96) to HBM and allocates the N x D
+ * fp32 embedding matrix there.  `device` is the HIP device ordinal. */
+int f2v_create(const uint32_t *rowptr, const uint32_t *colids, uint32_t n, uint64_t nnz, uint32_t dim, int device,
+               f2v_handle *out);
+int f2v_destroy(f2v_handle h);
+
+/* srand(seed) of Test/Force2Vec.cpp:126; the handle carries the libc rand() stream. */
+int f2v_srand(f2v_handle h, uint32_t seed);
+/* randInitF / randInit (sample/algorithms.cpp:38-53): N*D rand() draws, uploaded to HBM. */
+int f2v_init_embeddings(f2v_handle h, int kind);
+/* Direct access to the embedding matrix `nCoordinates` (sample/algorithms.h:55), host N x D row-major. */
+int f2v_set_embeddings(f2v_handle h, const float *x);
+int f2v_get_embeddings(f2v_handle h, float *x_out);
+
+/* Tunables: "hub_chunk" (neighbours per wave before a row is split; 0 = never split, the
+ * reference's summation order for every row), "waves_per_block". */
+int f2v_set_param(f2v_handle h, const char *name, int64_t value);
+int f2v_get_param(f2v_handle h, const char *name, int64_t *value_out);
+
+/* ---- training --------------------------------------------------------------------------
+ * Replaces vector<float> algorithms::AlgoForce2VecNS / NSBS / NSRW / NSRWBS / NSRWEFF and
+ * their AVX512 twins (sample/algorithms.h:86-102; bodies sample/algorithms.cpp:544-1203,
+ * 1230-4051): `iters` epochs of minibatch SGD over all N vertices in batches of `batch`,
+ * drawing negative samples (and, for option 7, walks) from the handle's rand() stream in
+ * the reference's order.  option: 5|6|7 (8,11 -> 5 ; 9 -> 6 ; 10 -> 7 maths).  bs_mode: the
+ * CLI's "-bs" (1 = ns*batch samples per minibatch, row i uses samples [i, i+ns)).
+ * seconds_out (may be NULL) receives the device time of the epoch loop alone (HIP events);
+ * the embeddings stay in HBM (fetch with f2v_get_embeddings). */
+int f2v_train(f2v_handle h, int option, uint32_t iters, uint32_t batch, uint32_t ns, float lr, int bs_mode,
+              double *seconds_out);
+
+/* One minibatch: the kgen row-kernel boundary Calc_<pre>frc_<tdist|sigmoid>_DIM<D>_VL<V>
+ * (sample/kgen/genDimFrc.base:36-57) lifted to a batch, and the unit the multi-GPU driver
+ * shards.  Computes the new embeddings of rows [row_lo,row_hi) of minibatch
+ * [batch_lo,batch_hi) from the pre-batch matrix and keeps them in the staging buffer; they
+ * become visible in the matrix when the next step / f2v_flush commits them (other ranks'
+ * rows are merged first with f2v_stage_write).  sample_ids: host array of the minibatch's
+ * negative-sample vertex ids (ns of them, or (batch_hi-batch_lo)+ns-1 in bs_mode).
+ * Option 7 uses the walks set by f2v_set_walks. */
+int f2v_minibatch_step(f2v_handle h, int option, uint32_t batch_lo, uint32_t batch_hi, uint32_t row_lo,
+                       uint32_t row_hi, const uint32_t *sample_ids, uint32_t n_sample_ids, uint32_t ns, float lr,
+                       int bs_mode);
+/* Commit the staged minibatch into the matrix (K5, sample/algorithms.cpp:629-639 / 913-921). */
+int f2v_flush(f2v_handle h);
+/* Option 7 walk samples of the current epoch, uint32[5*n] (sample/algorithms.cpp:1097-1118). */
+int f2v_set_walks(f2v_handle h, const uint32_t *walks);
+/* Draw this epoch's walks from the handle's rand() stream exactly as the reference does. */
+int f2v_generate_walks(f2v_handle h, uint32_t *walks_out /* may be NULL */);
+/* randIndex(max,min) of sample/algorithms.cpp:55-58 on the handle's stream. */
+int f2v_rand_index(f2v_handle h, uint32_t max_num, uint32_t min_num, uint32_t *out);
+
+/* Multi-GPU exchange: device address of the staged rows of the pending minibatch (row r of
+ * the batch at float offset (r-batch_lo)*dim), the number of rows it can hold, and a host
+ * read/write of a row range of it (gloo / test path). */
+int f2v_stage_device_ptr(f2v_handle h, uint64_t *devptr_out, uint32_t *capacity_rows_out);
+int f2v_stage_read(f2v_handle h, uint32_t row_lo, uint32_t row_hi, float *out);
+int f2v_stage_write(f2v_handle h, uint32_t row_lo, uint32_t row_hi, const float *in);
+int f2v_stage_reserve(f2v_handle h, uint32_t rows);
+/* Device address of the embedding matrix and the HIP stream (as integers) for zero-copy wrapping. */
+int f2v_embeddings_device_ptr(f2v_handle h, uint64_t *devptr_out);
+int f2v_stream(f2v_handle h, uint64_t *stream_out);
+int f2v_synchronize(f2v_handle h);
+
+/* Statistics of the last f2v_train: launches of the step kernel, rows and nonzeros they
+ * processed, algorithmic bytes (SURVEY 8d formula), device seconds. */
+typedef struct {
+    uint64_t step_launches;
+    uint64_t rows;
+    uint64_t nnz;
+    uint64_t algorithmic_bytes;
+    double device_seconds;
+    uint64_t hub_rows;
+    uint64_t hub_chunks;
+} f2v_stats;
+int f2v_get_stats(f2v_handle h, f2v_stats *out);
+
+/* ---- host-side I/O of the drop-in boundary (no device needed) ----------------------------
+ * f2v_read_mtx replaces SetInputMatricesAsCSR (sample/commonutility.h:44-54 -> ReadASCII
+ * sample/IO.h:59-156, CSC sample/CSC.h:146-188, CSR sample/CSR.h:154-186): MatrixMarket
+ * coordinate text; "symmetric" mirrors off-diagonal entries and drops self-loops;
+ * duplicates kept; colids ascending per row.  Arrays are malloc'ed; free with f2v_free. */
+int f2v_read_mtx(const char *path, uint32_t *n_out, uint64_t *nnz_out, uint32_t **rowptr_out, uint32_t **colids_out);
+void f2v_free(void *p);
+/* Replaces algorithms::writeToFile (sample/algorithms.h:118-136): "<N> <D>\n", then
+ * "<i+1> v0 v1 ... \n" with 6 significant digits (%g) and a trailing space. */
+int f2v_write_embd(const char *path, const float *x, uint32_t n, uint32_t dim);
+/* Output file name rule of writeToFile + the per-option suffixes (sample/algorithms.cpp:650,
+ * 752, 930, 1059, 1201, 1635, 2047, 2409, 2860): outdir + basename(input) + suffix + ".embd". */
+int f2v_output_name(const char *input, const char *outdir, int option, int bs_mode, uint32_t batch, uint32_t dim,
+                    uint32_t iters, uint32_t ns, char *out, size_t out_len);
+
+/* Stand-alone libc rand() stream (glibc TYPE_3), for hosts that pre-draw sample ids. */
+typedef struct f2v_rng f2v_rng;
+f2v_rng *f2v_rng_create(uint32_t seed);
+void f2v_rng_destroy(f2v_rng *g);
+int f2v_rng_next(f2v_rng *g);
+
+/* The 2048-entry sigmoid table of init_SM_TABLE (sample/algorithms.cpp:757-764) as the source defines it. */
+int f2v_sm_table(float *table_out /* 2048 */);
+
+/* ---- self-test hooks (used by tests/ only) ---------------------------------------------- */
+/* Runs the wavefront tree reduction on `rows` rows of `width` (<=512) floats; out[r] = sum. */
+int f2v_test_wave_reduce(int device, const float *in, uint32_t rows, uint32_t width, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* F2V_H_ */

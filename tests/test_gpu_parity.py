@@ -1,0 +1,230 @@
+"""-m gpu: the HIP path (through the C ABI of libf2v) against the CPU oracle.
+
+Bit-exact against the oracle's ORDER_TREE (the canonical wavefront reduction order the
+kernels implement, see oracle/f2v_oracle.c) -- every fp32 value identical; and within the
+fp32 tolerance stated per test against ORDER_REF / the committed reference goldens."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, ROOT, golden_graph_path
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def F():
+    import force2vec_amd as F
+    return F
+
+
+def tree_sum_model(rows):
+    rows = np.asarray(rows, dtype=np.float32)
+    r, w = rows.shape
+    P = 1
+    while P < w:
+        P *= 2
+    t = np.zeros((r, P), dtype=np.float32)
+    t[:, :w] = rows
+    while P > 1:
+        t = (t[:, 0:P:2] + t[:, 1:P:2]).astype(np.float32)
+        P //= 2
+    return t[:, 0]
+
+
+@pytest.mark.parametrize("width", [1, 3, 16, 64, 100, 128, 200, 256, 512])
+def test_wave_reduce_order(F, width):
+    import ctypes as C
+    from force2vec_amd import _lib
+    rng = np.random.default_rng(width)
+    x = (rng.standard_normal((37, width)) * 10 ** rng.uniform(-3, 3, (37, 1))).astype(np.float32)
+    out = np.empty(37, dtype=np.float32)
+    _lib.check(_lib.lib().f2v_test_wave_reduce(0, x.ctypes.data_as(_lib.f32p), 37, width, out.ctypes.data_as(_lib.f32p)))
+    assert np.array_equal(out, tree_sum_model(x))
+
+
+def random_graph(n, avg_deg, seed, hubs=()):
+    rng = np.random.default_rng(seed)
+    src = rng.integers(0, n, n * avg_deg // 2)
+    dst = rng.integers(0, n, n * avg_deg // 2)
+    for h, d in hubs:
+        nb = rng.choice(n, d, replace=False)
+        src = np.concatenate([src, np.full(d, h)])
+        dst = np.concatenate([dst, nb])
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    r = np.concatenate([src, dst])
+    c = np.concatenate([dst, src])  # duplicates kept, like the reference's reader
+    order = np.lexsort((c, r))
+    r, c = r[order], c[order]
+    rowptr = np.zeros(n + 1, dtype=np.uint32)
+    rowptr[1:] = np.cumsum(np.bincount(r, minlength=n))
+    return rowptr, c.astype(np.uint32)
+
+
+STEP_CASES = [
+    # option, dim, bs, chunk, n, batch
+    (5, 128, 0, 512, 300, 64), (5, 128, 0, 8, 300, 64), (5, 128, 1, 8, 300, 64), (5, 16, 0, 0, 200, 50),
+    (5, 64, 0, 4, 200, 50), (5, 100, 0, 4, 200, 50), (5, 256, 0, 16, 150, 70), (5, 512, 1, 5, 130, 33),
+    (5, 3, 0, 0, 90, 90), (6, 128, 0, 512, 300, 64), (6, 128, 1, 8, 300, 64), (6, 32, 0, 3, 200, 50),
+    (6, 200, 0, 7, 150, 64), (7, 128, 0, 512, 300, 64), (7, 48, 0, 512, 200, 37),
+]
+
+
+@pytest.mark.parametrize("option,dim,bs,chunk,n,batch", STEP_CASES)
+def test_minibatch_steps_bit_exact(F, option, dim, bs, chunk, n, batch):
+    """Several consecutive minibatches (incl. a ragged last one and a second epoch) through
+    f2v_minibatch_step, samples hitting the current batch, the previous batch and the row itself."""
+    rowptr, colids = random_graph(n, 6, seed=dim + option, hubs=((5, 40), (n - 3, 90)))
+    rng = np.random.default_rng(7)
+    X0 = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    eng = F.Engine(rowptr, colids, dim)
+    eng.set_param("hub_chunk", chunk)
+    eng.set_embeddings(X0)
+    Xo = X0.copy()
+    ns, lr = 5, 0.02
+    orng = O.Rng(3)
+    for epoch in range(2):
+        walks = None
+        if option == 7:
+            walks = O.generate_walks(orng, rowptr, colids)
+            eng.set_walks(walks)
+        for lo in range(0, n, batch):
+            hi = min(lo + batch, n)
+            nid = (hi - lo) + ns - 1 if bs else ns
+            ids = rng.integers(0, n - 1, nid).astype(np.uint32)
+            ids[0] = lo            # a row of the current batch (self-sample for row lo: NaN -> -5 path in option 5)
+            if lo > 0:
+                ids[1] = lo - 1    # a row of the previous (still staged) batch
+            eng.minibatch_step(option, lo, hi, ids, ns, lr, bs)
+            O.minibatch(option, rowptr, colids, Xo, lo, hi, ids, ns, lr, bs_mode=bs, walks=walks,
+                        order=O.ORDER_TREE, chunk=chunk)
+    got = eng.get_embeddings()
+    assert np.array_equal(got, Xo), float(np.abs(got - Xo).max())
+    eng.close()
+
+
+def test_sharded_rows_and_stage_exchange(F):
+    """The multi-GPU unit: two engines each compute half of every minibatch and exchange staged rows."""
+    n, dim, batch = 260, 128, 100
+    rowptr, colids = random_graph(n, 8, seed=11, hubs=((7, 60),))
+    rng = np.random.default_rng(1)
+    X0 = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    engs = [F.Engine(rowptr, colids, dim) for _ in range(2)]
+    for e in engs:
+        e.set_param("hub_chunk", 16)
+        e.set_embeddings(X0)
+    Xo = X0.copy()
+    for epoch in range(2):
+        for lo in range(0, n, batch):
+            hi = min(lo + batch, n)
+            ids = rng.integers(0, n - 1, 5).astype(np.uint32)
+            mid = lo + (hi - lo + 1) // 2
+            engs[0].minibatch_step(5, lo, hi, ids, 5, 0.02, 0, row_lo=lo, row_hi=mid)
+            engs[1].minibatch_step(5, lo, hi, ids, 5, 0.02, 0, row_lo=mid, row_hi=hi)
+            a = engs[0].stage_read(lo, mid)
+            b = engs[1].stage_read(mid, hi)
+            engs[0].stage_write(mid, hi, b)
+            engs[1].stage_write(lo, mid, a)
+            O.minibatch(5, rowptr, colids, Xo, lo, hi, ids, 5, 0.02, order=O.ORDER_TREE, chunk=16)
+    for e in engs:
+        assert np.array_equal(e.get_embeddings(), Xo)
+        e.close()
+
+
+TRAIN_CASES = [("karate.mtx", 5, 10, 16, 16, 0), ("karate.mtx", 5, 10, 7, 16, 1), ("karate.mtx", 5, 3, 64, 128, 0),
+               ("karate.mtx", 6, 10, 16, 16, 0), ("karate.mtx", 6, 10, 7, 32, 1), ("karate.mtx", 7, 10, 16, 16, 0),
+               ("karate.mtx", 7, 5, 5, 128, 0), ("cora.mtx", 5, 10, 256, 16, 0), ("cora.mtx", 5, 10, 256, 128, 0),
+               ("cora.mtx", 5, 10, 384, 128, 0), ("cora.mtx", 5, 5, 256, 64, 1), ("cora.mtx", 6, 10, 256, 128, 0),
+               ("cora.mtx", 6, 5, 256, 64, 1), ("cora.mtx", 7, 10, 256, 128, 0), ("citeseer.mtx", 5, 5, 500, 32, 0)]
+
+
+@pytest.mark.parametrize("graph,option,iters,batch,dim,bs", TRAIN_CASES)
+def test_train_bit_exact_vs_oracle_and_close_to_reference(F, graph, option, iters, batch, dim, bs, manifest):
+    """f2v_train from srand(1): identical to the oracle in tree order; within 2e-5 (<= 10 epochs, the
+    BASELINE.md divergence curve) of the genuine reference's .embd where a golden text is committed."""
+    rowptr, colids = F.read_mtx(golden_graph_path(graph))
+    algo = F.algorithms((rowptr, colids), dim=dim)
+    algo.engine.set_param("hub_chunk", 64)
+    algo.srand(1)
+    algo._run(option, bs, iters, batch, 5, 0.02, write=False)
+    want = O.train(option, rowptr, colids, dim, iters, batch, bs_mode=bs, order=O.ORDER_TREE, chunk=64)
+    assert np.array_equal(algo.nCoordinates, want), float(np.abs(algo.nCoordinates - want).max())
+    name = "%s_opt%d_it%d_B%d_D%d_bs%d" % (graph.replace(".mtx", ""), option, iters, batch, dim, bs)
+    gz = os.path.join(GOLD, name + ".embd.gz")
+    if os.path.exists(gz):
+        tmp = "/tmp/f2v_%s.embd" % name
+        with gzip.open(gz, "rb") as fi, open(tmp, "wb") as fo:
+            fo.write(fi.read())
+        ref = O.read_embd(tmp)
+        # golden text has 6 significant digits: 5e-6 print resolution for |x| < 10, plus the fp32 order tolerance
+        assert np.abs(algo.nCoordinates - ref).max() < 3e-5
+    algo.engine.close()
+
+
+def test_options_8_to_11_alias_the_same_maths(F):
+    rowptr, colids = F.read_mtx(golden_graph_path("karate.mtx"))
+    res = {}
+    for opt in (5, 8, 11, 6, 9, 7, 10):
+        a = F.algorithms((rowptr, colids), dim=128)
+        a.srand(1)
+        a._run(opt, 0, 3, 16, 5, 0.02, write=False)
+        res[opt] = a.nCoordinates
+        a.engine.close()
+    assert np.array_equal(res[5], res[8]) and np.array_equal(res[5], res[11])
+    assert np.array_equal(res[6], res[9]) and np.array_equal(res[7], res[10])
+
+
+def test_cli_drop_in(F, tmp_path):
+    """./bin/Force2Vec with the reference's flags: file name, .embd text, Results.txt, exit codes."""
+    exe = os.path.join(ROOT, "bin", "Force2Vec")
+    out = str(tmp_path) + "/"
+    r = subprocess.run([exe, "-input", golden_graph_path("cora.mtx"), "-output", out, "-iter", "10", "-batch", "256",
+                        "-dim", "128", "-option", "5", "-nsamples", "5", "-lr", "0.02"], cwd=out, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    path = out + "cora.mtxF2VNS256D128IT10NS5.embd"
+    assert os.path.exists(path) and "Wall time required:" in r.stdout
+    assert "Algo:Force2Vec:t-distribution with negative sampling\tInit:RAND\tIteration:10" in open(out + "Results.txt").read()
+    got = O.read_embd(path)
+    rowptr, colids = O.read_mtx(golden_graph_path("cora.mtx"))
+    want = O.train(5, rowptr, colids, 128, 10, 256, order=O.ORDER_TREE, chunk=512)
+    wtxt = str(tmp_path / "want.embd")
+    O.write_embd(wtxt, want)
+    assert open(path, "rb").read() == open(wtxt, "rb").read()      # same floats -> same text
+    with gzip.open(os.path.join(GOLD, "cora_opt5_it10_B256_D128_bs0.embd.gz"), "rb") as f:
+        open(str(tmp_path / "ref.embd"), "wb").write(f.read())
+    assert np.abs(got - O.read_embd(str(tmp_path / "ref.embd"))).max() < 3e-5
+
+
+def test_full_size_sampled_rows(F):
+    """RMAT scale-16 (65 536 vertices, ~1 M nnz, hubs of thousands of neighbours) at D = 128: one
+    epoch in 4 minibatches, checked on sampled rows (hubs included) against the oracle's row
+    function applied to the downloaded pre-step matrix, plus determinism of a second run."""
+    from force2vec_amd.graph import rmat_csr
+    rowptr, colids = rmat_csr(16, 16, seed=1)
+    n, dim, batch = len(rowptr) - 1, 128, 16384
+    deg = np.diff(rowptr.astype(np.int64))
+    rng = np.random.default_rng(5)
+    eng = F.Engine(rowptr, colids, dim)
+    eng.srand(1)
+    eng.init_embeddings(0)
+    chunk = eng.get_param("hub_chunk")
+    assert deg.max() > chunk
+    for lo in range(0, n, batch):
+        hi = lo + batch
+        before = eng.get_embeddings()
+        ids = rng.integers(0, n - 1, 5).astype(np.uint32)
+        eng.minibatch_step(5, lo, hi, ids, 5, 0.02)
+        after = eng.get_embeddings()
+        rows = np.concatenate([rng.integers(lo, hi, 40), lo + np.argsort(deg[lo:hi])[-4:]])
+        for i in rows:
+            want = O.row(5, rowptr, colids, before, int(i), ids, 0.02, order=O.ORDER_TREE, chunk=chunk)
+            assert np.array_equal(after[i], want), (i, deg[i])
+        outside = np.ones(n, bool)
+        outside[lo:hi] = False
+        assert np.array_equal(after[outside], before[outside])
+    eng.close()
