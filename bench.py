@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py -- edges/sec of the Force2Vec hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one epoch = one pass of the hot path over every minibatch of the synthetic
+graph (BASELINE.json configs[2]: RMAT scale-20, ~1 M vertices / ~16 M undirected edges,
+option 5, D = 128, ns = 5).  edges/sec = nnz * K / T (nnz = directed CSR nonzeros, the
+reference's unit).  Inputs are resident in HBM when the timed region starts.
+N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL): the SAME graph and
+epochs, each minibatch's rows sharded over the ranks (force2vec_amd/dist.py) -- strong scaling.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` (HBM bound,
+algorithmic bytes / launch over the live HIP-event launch time) and `cpu_baseline` (the genuine
+reference binary oracle/_ref timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def load_graph(scale, edge_factor, seed):
+    """RMAT CSR, cached under /tmp (generation is setup, not measured)."""
+    from force2vec_amd.graph import rmat_csr
+    cache = "/tmp/f2v_rmat_s%d_e%d_seed%d.npz" % (scale, edge_factor, seed)
+    if os.path.exists(cache):
+        try:
+            z = np.load(cache)
+            return z["rowptr"], z["colids"]
+        except Exception:
+            pass
+    t0 = time.time()
+    rowptr, colids = rmat_csr(scale, edge_factor, seed)
+    log("bench: generated RMAT scale %d: n=%d nnz=%d in %.1fs" % (scale, len(rowptr) - 1, len(colids), time.time() - t0))
+    try:
+        tmp = cache + ".%d.tmp.npz" % os.getpid()
+        np.savez(tmp, rowptr=rowptr, colids=colids)
+        os.replace(tmp, cache)
+    except Exception:
+        pass
+    return rowptr, colids
+
+
+def cpu_baseline(args):
+    """The reference on this box's host cores, on a bounded sample of the same workload: a smaller RMAT
+    graph (scale args.cpu_scale), same D / ns / lr / batch.  T(iters=k) - T(iters=0) strips the reference's
+    in-timer initialisation.  kind 'reference' = oracle/_ref (the genuine reference, built from
+    /root/reference by oracle/build_ref.sh); fallback kind 'port' = the single-thread C oracle."""
+    from force2vec_amd.graph import edges_from_csr, write_mtx_symmetric
+    from oracle import oracle as O
+    rowptr, colids = load_graph(args.cpu_scale, 16, 1)
+    n, nnz = len(rowptr) - 1, len(colids)
+    cores = os.cpu_count() or 1
+    flags = open("/proc/cpuinfo").read()
+    avx512 = (" avx512f" in flags) and (" avx512dq" in flags) and O.ref_binary(True) is not None
+    exe_ok = O.ref_binary(avx512) is not None
+    sample = "RMAT scale-%d (n=%d, nnz=%d), D=%d ns=5 lr=0.02 batch=%d" % (args.cpu_scale, n, nnz, args.dim, args.batch)
+    if exe_ok:
+        option = 11 if avx512 else 5
+        with tempfile.TemporaryDirectory() as td:
+            mtx = os.path.join(td, "sample.mtx")
+            src, dst = edges_from_csr(rowptr, colids)
+            write_mtx_symmetric(mtx, n, src, dst)
+
+            def run(iters):
+                out = run_ref(O, mtx, td, option, iters, args, cores, avx512)
+                for line in out.splitlines():
+                    if "Wall time required" in line:
+                        return float(line.split(":")[-1].split()[0])
+                raise RuntimeError("reference output not understood:\n" + out)
+
+            t0 = run(0)
+            k = args.cpu_iters
+            tk = run(k)
+            # aim for >= ~10 s of CPU work
+            if tk - t0 < 5.0:
+                k2 = int(min(400, max(k + 1, k * 10.0 / max(tk - t0, 1e-3))))
+                tk, k = run(k2), k2
+        val = nnz * k / max(tk - t0, 1e-9)
+        return {"value": val, "unit": "edges/s", "cores": cores, "kind": "reference",
+                "sample": "%s; oracle/_ref option %d%s, %d epochs in %.2fs, -threads %d" % (sample, option, " (AVX512 build)" if avx512 else " (scalar build)", k, tk - t0, cores)}
+    # port: single-thread oracle, a few epochs
+    X = O.Rng(1).init_embeddings(n, args.dim, 0)
+    t0 = time.time()
+    O.train(5, rowptr, colids, args.dim, 1, args.batch, X0=X)
+    dt = time.time() - t0
+    return {"value": nnz / dt, "unit": "edges/s", "cores": 1, "kind": "port", "sample": sample + "; oracle/f2v_oracle.c, 1 epoch in %.2fs" % dt}
+
+
+def run_ref(O, mtx, td, option, iters, args, cores, avx512):
+    exe = O.ref_binary(avx512)
+    cmd = [exe, "-input", mtx, "-output", "/nonexistent_dir_so_no_embd_is_written/", "-iter", str(iters), "-batch", str(args.batch),
+           "-dim", str(args.dim), "-nsamples", "5", "-lr", "0.02", "-option", str(option), "-threads", str(cores)]
+    out = subprocess.run(cmd, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, check=True).stdout
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scale", type=int, default=20, help="RMAT scale (2^scale vertices, edge factor 16)")
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--batch", type=int, default=65536)
+    ap.add_argument("--option", type=int, default=5)
+    ap.add_argument("--hub-chunk", type=int, default=-1)
+    ap.add_argument("--cpu-scale", type=int, default=17)
+    ap.add_argument("--cpu-iters", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extra-batches", type=str, default="256,4096,16384", help="comma list of further batch sizes to time (reported under 'extra')")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import force2vec_amd as F
+    from force2vec_amd import dist as fdist
+
+    dist = None
+    torch = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    rowptr, colids = load_graph(args.scale, 16, 1)
+    n, nnz = len(rowptr) - 1, len(colids)
+    eng = F.Engine(rowptr, colids, args.dim, device=local_rank)
+    if args.hub_chunk >= 0:
+        eng.set_param("hub_chunk", args.hub_chunk)
+    eng.srand(1)
+    eng.init_embeddings(F._lib.INIT_SYMMETRIC if args.option in (5, 8, 11) else F._lib.INIT_UNIT)
+
+    def barrier():
+        eng.synchronize()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def run_epochs(k, batch):
+        if world == 1:
+            eng.train(args.option, k, batch, 5, 0.02, 0)
+            return eng.stats()
+        comm = fdist.NcclStageComm(dist, rank, world, local_rank)
+        fdist.ShardedTrainer(eng, rank, world, comm).train(args.option, k, batch, 5, 0.02, 0)
+        return None
+
+    def timed(k, w, batch):
+        if w > 0:
+            run_epochs(w, batch)
+        barrier()
+        t0 = time.perf_counter()
+        st = run_epochs(k, batch)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, st
+
+    dt, st = timed(args.steps, args.warmup, args.batch)
+    value = nnz * args.steps / dt
+    res = {
+        "metric": "embedding edges/sec at D=%d, option %d" % (args.dim, args.option),
+        "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "RMAT scale-%d edge-factor 16 (n=%d, nnz=%d directed CSR nonzeros), option %d, D=%d, ns=5, lr=0.02, batch=%d; step = 1 epoch"
+                   % (args.scale, n, nnz, args.option, args.dim, args.batch),
+                   "batch": args.batch, "hub_chunk": eng.get_param("hub_chunk"),
+                   "parallelism": "1 GPU" if world == 1 else "minibatch rows sharded over %d GPUs, replicated graph+matrix, RCCL all-gather of staged rows" % world},
+    }
+    if st is not None:
+        # dominant kernel = step_kernel, one launch per minibatch; launch time from HIP events on the
+        # engine's stream around the epoch loop (f2v_train), algorithmic bytes per SURVEY 8d
+        per_launch = st["algorithmic_bytes"] / max(st["step_launches"], 1)
+        t_launch = st["device_seconds"] / max(st["step_launches"], 1)
+        ach = per_launch / t_launch * 1e-9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tp):
+            try:
+                tj = json.load(open(tp))
+                if tj.get("batch") == args.batch and tj.get("scale") == args.scale and tj.get("dim") == args.dim:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+        res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                           "traffic": traffic, "kernel": "step_kernel<5,2,true>", "algorithmic_bytes_per_launch": per_launch,
+                           "avg_launch_us": t_launch * 1e6, "launches": st["step_launches"]}
+    if rank == 0 and world == 1:
+        extra = {}
+        for b in [int(x) for x in args.extra_batches.split(",") if x]:
+            dtb, stb = timed(max(1, args.steps // 2), 1, b)
+            k = max(1, args.steps // 2)
+            extra["batch_%d" % b] = {"edges_per_s": nnz * k / dtb, "ms_per_epoch": dtb / k * 1e3,
+                                     "hbm_GBs": stb["algorithmic_bytes"] / stb["device_seconds"] * 1e-9}
+        if extra:
+            res["extra"] = extra
+        if not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(args)
+            except Exception as ex:  # the baseline is reported, never required for the GPU number
+                res["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": os.cpu_count(), "kind": "reference", "sample": "failed: %r" % (ex,)}
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+
+
+if __name__ == "__main__":
+    main()

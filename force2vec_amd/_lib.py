@@ -38,6 +38,7 @@ SIGNATURES = {
     "f2v_set_walks": (C.c_int, [C.c_void_p, u32p]),
     "f2v_generate_walks": (C.c_int, [C.c_void_p, u32p]),
     "f2v_rand_index": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, u32p]),
+    "f2v_rand_indices": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, u32p]),
     "f2v_stage_device_ptr": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), u32p]),
     "f2v_stage_read": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, f32p]),
     "f2v_stage_write": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, f32p]),

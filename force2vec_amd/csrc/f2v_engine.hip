@@ -14,7 +14,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
+#include <tuple>
 #include <type_traits>
 #include <vector>
 
@@ -32,6 +34,16 @@ using namespace f2v;
                         hipGetErrorString(e__), __FILE__, __LINE__);                                   \
     } while (0)
 
+constexpr int kMaxFinLevels = 32;  // fan-in >= 2: 2^32 chunks
+struct Plan {
+    size_t item_off = 0;
+    uint32_t n_items = 0, n_hubs = 0, n_chunks = 0, n_slots = 0;
+    int n_levels = 0;  // levels of the hub combine trees
+    size_t fin_off[kMaxFinLevels] = {};
+    uint32_t fin_cnt[kMaxFinLevels] = {};
+    uint64_t nnz = 0;
+};
+
 struct f2v_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -46,12 +58,17 @@ struct f2v_ctx {
     uint32_t stage_cap = 0;
     bool have_x = false, have_walks = false;
     Rand rng;
-    // hub plan for the current chunk size
-    uint32_t chunk = 512, plan_chunk = 0xFFFFFFFFu;
-    std::vector<uint32_t> hub_rows;     // rows with degree > chunk, ascending
-    std::vector<uint32_t> hub_prefix;   // chunk-count prefix over hub_rows
-    uint2 *d_extras = nullptr;
-    HubRow *d_hubs = nullptr;
+    // work-item plans (one per distinct launch: row range x neighbour source), see plan_for()
+    uint32_t chunk = 64, fanin = 32;
+    bool chunk_auto = true;  // f2v_train / "hub_chunk_for_batch" pick the chunk from the batch size
+    bool use_quarter = true;  // quarter-wave kernel when D is 64, 128 or 256
+    std::map<std::tuple<uint32_t, uint32_t, int>, Plan> plans;
+    std::vector<Item> h_items;
+    std::vector<FinItem> h_hubs;
+    Item *d_items = nullptr;
+    FinItem *d_hubs = nullptr;
+    size_t d_items_cap = 0, d_hubs_cap = 0, d_items_valid = 0, d_hubs_valid = 0;
+    size_t partial_slots = 0, max_slots = 0;
     // pending (staged, not yet committed) minibatch
     bool pending = false;
     uint32_t p_lo = 0, p_hi = 0;
@@ -68,35 +85,126 @@ int pick_vec(uint32_t D) {
     return v;
 }
 
-int build_hub_plan(f2v_ctx *c) {
-    if (c->plan_chunk == c->chunk) return F2V_OK;
-    c->hub_rows.clear();
-    c->hub_prefix.assign(1, 0u);
-    if (c->d_extras) { (void)hipFree(c->d_extras); c->d_extras = nullptr; }
-    if (c->d_hubs) { (void)hipFree(c->d_hubs); c->d_hubs = nullptr; }
-    if (c->d_partials) { (void)hipFree(c->d_partials); c->d_partials = nullptr; }
-    if (c->chunk != 0) {
-        std::vector<uint2> extras;
-        std::vector<HubRow> hubs;
-        for (uint32_t i = 0; i < c->n; i++) {
-            const uint32_t deg = c->rowptr[i + 1] - c->rowptr[i];
-            if (deg > c->chunk) {
-                const uint32_t nc = (deg + c->chunk - 1) / c->chunk;
-                hubs.push_back(HubRow{i, (uint32_t)extras.size(), nc});
-                for (uint32_t k = 0; k < nc; k++) extras.push_back(make_uint2(i, k));
-                c->hub_rows.push_back(i);
-                c->hub_prefix.push_back((uint32_t)extras.size());
-            }
+// Hub chunk for minibatches of `batch` rows: a chunk is one quarter-wave's serial stretch (about
+// 0.6 us per neighbour), the launch as a whole streams ~516 B per nonzero at ~6 TB/s; keeping the
+// longest stretch at about half the launch's streaming time gives chunk ~ batch nonzeros / 14000
+// (measured optimum on RMAT-20: 16 at B=4096, 32 at B=16384, 128 at B=65536).  It depends only on
+// the graph and the batch size, never on the number of ranks, so results do not change with -gpus.
+uint32_t auto_chunk(const f2v_ctx *c, uint32_t batch) {
+    const double est = (double)std::min(batch, c->n) * ((double)c->nnz / (double)c->n) / 14000.0;
+    uint32_t ch = 8;
+    while (ch < 512 && (double)ch * 1.5 < est) ch <<= 1;
+    return ch;
+}
+
+void drop_plans(f2v_ctx *c) {
+    c->plans.clear();
+    c->max_slots = 0;
+    c->h_items.clear();
+    c->h_hubs.clear();
+    c->d_items_valid = c->d_hubs_valid = 0;
+}
+
+// Work items of one launch (rows [row_lo,row_hi), CSR neighbours or walk samples): a whole row, or
+// `chunk`-neighbour pieces of a hub row, sorted longest first (the longest waves start first and
+// the four quarters of a wave get items of nearly equal length).  Host-side, cached per launch shape.
+const Plan &plan_for(f2v_ctx *c, uint32_t row_lo, uint32_t row_hi, bool walk) {
+    const auto key = std::make_tuple(row_lo, row_hi, walk ? 1 : 0);
+    auto itp = c->plans.find(key);
+    if (itp != c->plans.end()) return itp->second;
+    if (c->h_items.size() > 8 * ((size_t)c->n + 1024)) drop_plans(c);  // bound the cache
+    Plan p;
+    p.item_off = c->h_items.size();
+    std::vector<Item> items;
+    items.reserve(row_hi - row_lo);
+    struct Node { uint32_t row, in_slot, n; };
+    std::vector<Node> cur, nxt;
+    uint32_t slots = 0;
+    for (uint32_t i = row_lo; i < row_hi; i++) {
+        if (walk) {
+            items.push_back(Item{i, i * (uint32_t)kWalkLength, (uint32_t)kWalkLength, kItemFirst | kItemLast});
+            p.nnz += kWalkLength;
+            continue;
         }
-        if (!extras.empty()) {
-            HIPC(hipMalloc((void **)&c->d_extras, extras.size() * sizeof(uint2)));
-            HIPC(hipMalloc((void **)&c->d_hubs, hubs.size() * sizeof(HubRow)));
-            HIPC(hipMalloc((void **)&c->d_partials, extras.size() * (size_t)c->D * sizeof(float)));
-            HIPC(hipMemcpy(c->d_extras, extras.data(), extras.size() * sizeof(uint2), hipMemcpyHostToDevice));
-            HIPC(hipMemcpy(c->d_hubs, hubs.data(), hubs.size() * sizeof(HubRow), hipMemcpyHostToDevice));
+        const uint32_t rp = c->rowptr[i], deg = c->rowptr[i + 1] - rp;
+        p.nnz += deg;
+        if (c->chunk != 0 && deg > c->chunk) {
+            const uint32_t nc = (deg + c->chunk - 1) / c->chunk;
+            cur.push_back(Node{i, slots, nc});
+            for (uint32_t k = 0; k < nc; k++) {
+                const uint32_t b = k * c->chunk, e = std::min(deg, b + c->chunk);
+                items.push_back(Item{i, rp + b, e - b, kItemPartial | (k == 0 ? kItemFirst : 0u) | (k == nc - 1 ? kItemLast : 0u) | (slots + k)});
+            }
+            slots += nc;
+        } else {
+            items.push_back(Item{i, rp, deg, kItemFirst | kItemLast});
         }
     }
-    c->plan_chunk = c->chunk;
+    std::stable_sort(items.begin(), items.end(), [](const Item &x, const Item &y) { return x.cnt > y.cnt; });
+    c->h_items.insert(c->h_items.end(), items.begin(), items.end());
+    p.n_items = (uint32_t)items.size();
+    p.n_hubs = (uint32_t)cur.size();
+    p.n_chunks = slots;
+    // combine trees, level by level: groups of `fanin` partials are added in order until one is left
+    while (!cur.empty() && p.n_levels < kMaxFinLevels) {
+        p.fin_off[p.n_levels] = c->h_hubs.size();
+        nxt.clear();
+        for (const Node &nd : cur) {
+            const uint32_t G = (p.n_levels == kMaxFinLevels - 1 || c->fanin < 2) ? nd.n : c->fanin;
+            const uint32_t nout = (nd.n + G - 1) / G;
+            if (nout == 1) {
+                c->h_hubs.push_back(FinItem{nd.in_slot, nd.n, kFinToStage, nd.row});
+            } else {
+                for (uint32_t o = 0; o < nout; o++)
+                    c->h_hubs.push_back(FinItem{nd.in_slot + o * G, std::min(G, nd.n - o * G), slots + o, nd.row});
+                nxt.push_back(Node{nd.row, slots, nout});
+                slots += nout;
+            }
+        }
+        p.fin_cnt[p.n_levels] = (uint32_t)(c->h_hubs.size() - p.fin_off[p.n_levels]);
+        p.n_levels++;
+        cur.swap(nxt);
+    }
+    p.n_slots = slots;
+    c->max_slots = std::max<size_t>(c->max_slots, slots);
+    return c->plans.emplace(key, p).first->second;
+}
+
+// Make every plan built so far resident in HBM (and the partial-sum buffer large enough).
+int upload_plans(f2v_ctx *c) {
+    const size_t need_slots = c->max_slots;
+    const bool grow_items = c->h_items.size() > c->d_items_cap, grow_hubs = c->h_hubs.size() > c->d_hubs_cap;
+    const bool grow_slots = need_slots > c->partial_slots;
+    if (c->h_items.size() == c->d_items_valid && c->h_hubs.size() == c->d_hubs_valid && !grow_slots) return F2V_OK;  // O(1) steady state
+    HIPC(hipStreamSynchronize(c->stream));  // launches in flight read these buffers
+    if (grow_items) {
+        if (c->d_items) (void)hipFree(c->d_items);
+        c->d_items = nullptr;
+        c->d_items_cap = std::max<size_t>(c->h_items.size() * 3 / 2, 1024);
+        HIPC(hipMalloc((void **)&c->d_items, c->d_items_cap * sizeof(Item)));
+        c->d_items_valid = 0;
+    }
+    if (grow_hubs) {
+        if (c->d_hubs) (void)hipFree(c->d_hubs);
+        c->d_hubs = nullptr;
+        c->d_hubs_cap = std::max<size_t>(c->h_hubs.size() * 3 / 2, 256);
+        HIPC(hipMalloc((void **)&c->d_hubs, c->d_hubs_cap * sizeof(FinItem)));
+        c->d_hubs_valid = 0;
+    }
+    if (grow_slots) {
+        if (c->d_partials) (void)hipFree(c->d_partials);
+        c->d_partials = nullptr;
+        HIPC(hipMalloc((void **)&c->d_partials, need_slots * (size_t)c->D * sizeof(float)));
+        c->partial_slots = need_slots;
+    }
+    if (c->h_items.size() > c->d_items_valid)
+        HIPC(hipMemcpy(c->d_items + c->d_items_valid, c->h_items.data() + c->d_items_valid,
+                       (c->h_items.size() - c->d_items_valid) * sizeof(Item), hipMemcpyHostToDevice));
+    if (c->h_hubs.size() > c->d_hubs_valid)
+        HIPC(hipMemcpy(c->d_hubs + c->d_hubs_valid, c->h_hubs.data() + c->d_hubs_valid,
+                       (c->h_hubs.size() - c->d_hubs_valid) * sizeof(FinItem), hipMemcpyHostToDevice));
+    c->d_items_valid = c->h_items.size();
+    c->d_hubs_valid = c->h_hubs.size();
     return F2V_OK;
 }
 
@@ -185,7 +293,8 @@ int launch_step(f2v_ctx *c, int math, uint32_t batch_lo, uint32_t batch_hi, uint
         if ((rc = reserve_stage(c, brows)) != F2V_OK) return rc;
     }
     const bool walk = (math == 7);
-    if ((rc = build_hub_plan(c)) != F2V_OK) return rc;
+    const Plan plan = plan_for(c, row_lo, row_hi, walk);  // by value: upload_plans may not move it, but keep it simple
+    if ((rc = upload_plans(c)) != F2V_OK) return rc;
     const int cur = c->pending ? (c->p_idx ^ 1) : 0;
 
     StepArgs a{};
@@ -194,55 +303,54 @@ int launch_step(f2v_ctx *c, int math, uint32_t batch_lo, uint32_t batch_hi, uint
     a.nbr_ids = walk ? c->d_walks : c->d_colids;
     a.stage_prev = c->pending ? c->d_stage[c->p_idx] : nullptr;
     a.stage_cur = c->d_stage[cur];
+    a.partials = c->d_partials;
     a.sample_ids = d_ids;
+    a.items = c->d_items + plan.item_off;
     a.sm_table = c->d_table;
     a.D = c->D;
     a.batch_lo = batch_lo;
-    a.row_lo = row_lo;
-    a.n_rows = row_hi - row_lo;
+    a.n_items = plan.n_items;
     a.prev_lo = c->pending ? c->p_lo : 0;
     a.prev_rows = c->pending ? (c->p_hi - c->p_lo) : 0;
     a.ns = ns;
     a.bs_mode = bs_mode ? 1u : 0u;
-    a.chunk = walk ? 0u : c->chunk;
-    a.walk_mode = walk ? 1u : 0u;
     a.lr = lr;
-    uint32_t h0 = 0, h1 = 0;
-    if (!walk && c->chunk != 0 && !c->hub_rows.empty()) {
-        h0 = (uint32_t)(std::lower_bound(c->hub_rows.begin(), c->hub_rows.end(), row_lo) - c->hub_rows.begin());
-        h1 = (uint32_t)(std::lower_bound(c->hub_rows.begin(), c->hub_rows.end(), row_hi) - c->hub_rows.begin());
-    }
-    const uint32_t slot_base = h1 > h0 ? c->hub_prefix[h0] : 0;
-    a.n_extra = h1 > h0 ? c->hub_prefix[h1] - slot_base : 0;
-    a.extras = h1 > h0 ? c->d_extras + slot_base : nullptr;
-    a.partials = h1 > h0 ? c->d_partials + (size_t)slot_base * c->D : nullptr;
 
     const uint32_t wpb = (uint32_t)c->waves_per_block;
-    const uint32_t items = a.n_extra + a.n_rows;
+    const bool quarter = c->use_quarter && c->exact && (c->D == 64 || c->D == 128 || c->D == 256);
+    const uint32_t per_wave = quarter ? 4u : 1u;
+    const uint32_t waves = (plan.n_items + per_wave - 1) / per_wave;
     // enough blocks for the items; when a rank has few or no rows of this batch, still enough to commit the pending one
-    const uint32_t blocks = std::max<uint32_t>(std::max<uint32_t>(1u, (items + wpb - 1) / wpb),
-                                               std::min<uint32_t>((a.prev_rows + wpb - 1) / wpb, 2048u));
-    rc = dispatch_layout(c, [&](auto V, auto E) {
-        constexpr int VEC = decltype(V)::value;
-        constexpr bool EX = decltype(E)::value;
-        if (math == 5)
-            hipLaunchKernelGGL((step_kernel<5, VEC, EX>), dim3(blocks), dim3(64 * wpb), 0, c->stream, a);
-        else
-            hipLaunchKernelGGL((step_kernel<6, VEC, EX>), dim3(blocks), dim3(64 * wpb), 0, c->stream, a);
-    });
-    if (rc != F2V_OK) return rc;
+    const uint32_t commit_waves = std::min<uint32_t>((a.prev_rows + per_wave - 1) / per_wave, 8192u);
+    const uint32_t blocks = std::max<uint32_t>(1u, (std::max(waves, commit_waves) + wpb - 1) / wpb);
+    if (quarter) {
+        const int nb = (int)(c->D / 64);
+#define F2V_Q(OPT, NB) hipLaunchKernelGGL((qstep_kernel<OPT, NB>), dim3(blocks), dim3(64 * wpb), 0, c->stream, a)
+        if (math == 5) { if (nb == 1) F2V_Q(5, 1); else if (nb == 2) F2V_Q(5, 2); else F2V_Q(5, 4); }
+        else { if (nb == 1) F2V_Q(6, 1); else if (nb == 2) F2V_Q(6, 2); else F2V_Q(6, 4); }
+#undef F2V_Q
+    } else {
+        rc = dispatch_layout(c, [&](auto V, auto E) {
+            constexpr int VEC = decltype(V)::value;
+            constexpr bool EX = decltype(E)::value;
+            if (math == 5)
+                hipLaunchKernelGGL((step_kernel<5, VEC, EX>), dim3(blocks), dim3(64 * wpb), 0, c->stream, a);
+            else
+                hipLaunchKernelGGL((step_kernel<6, VEC, EX>), dim3(blocks), dim3(64 * wpb), 0, c->stream, a);
+        });
+        if (rc != F2V_OK) return rc;
+    }
     HIPC(hipGetLastError());
-    if (h1 > h0) {
+    for (int lev = 0; lev < plan.n_levels; lev++) {
         FinalizeArgs f{};
         f.X = c->d_X;
-        f.partials = a.partials;
+        f.partials = c->d_partials;
         f.stage_cur = a.stage_cur;
-        f.hubs = c->d_hubs + h0;
-        f.slot_base = slot_base;
-        f.n_hubs = h1 - h0;
+        f.items = c->d_hubs + plan.fin_off[lev];
+        f.n_items = plan.fin_cnt[lev];
         f.D = c->D;
         f.batch_lo = batch_lo;
-        const uint32_t fb = (f.n_hubs + 3) / 4;
+        const uint32_t fb = (f.n_items + 3) / 4;
         rc = dispatch_layout(c, [&](auto V, auto E) {
             constexpr int VEC = decltype(V)::value;
             constexpr bool EX = decltype(E)::value;
@@ -253,21 +361,20 @@ int launch_step(f2v_ctx *c, int math, uint32_t batch_lo, uint32_t batch_hi, uint
         });
         if (rc != F2V_OK) return rc;
         HIPC(hipGetLastError());
-        c->stats.hub_rows += f.n_hubs;
-        c->stats.hub_chunks += a.n_extra;
     }
+    c->stats.hub_rows += plan.n_hubs;
+    c->stats.hub_chunks += plan.n_chunks;
     c->pending = true;
     c->p_lo = batch_lo;
     c->p_hi = batch_hi;
     c->p_idx = cur;
 
     // statistics: algorithmic bytes of SURVEY 8d -- nnz*(4D+4) + rows*(8D+4) + ns*(4D+4) per minibatch
-    const uint64_t rows = a.n_rows;
-    const uint64_t nz = walk ? rows * kWalkLength : (uint64_t)(c->rowptr[row_hi] - c->rowptr[row_lo]);
+    const uint64_t rows = row_hi - row_lo;
     c->stats.step_launches += 1;
     c->stats.rows += rows;
-    c->stats.nnz += nz;
-    c->stats.algorithmic_bytes += nz * (4ull * c->D + 4) + rows * (8ull * c->D + 4) + (uint64_t)ns * (4ull * c->D + 4);
+    c->stats.nnz += plan.nnz;
+    c->stats.algorithmic_bytes += plan.nnz * (4ull * c->D + 4) + rows * (8ull * c->D + 4) + (uint64_t)ns * (4ull * c->D + 4);
     return F2V_OK;
 }
 
@@ -349,7 +456,7 @@ int f2v_destroy(f2v_handle c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_rowptr, c->d_colids, c->d_walks, c->d_ids, c->d_X, c->d_stage[0], c->d_stage[1],
-                    c->d_partials, c->d_table, c->d_extras, c->d_hubs};
+                    c->d_partials, c->d_table, c->d_items, c->d_hubs};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -366,6 +473,15 @@ int f2v_srand(f2v_handle c, uint32_t seed) {
 int f2v_rand_index(f2v_handle c, uint32_t max_num, uint32_t min_num, uint32_t *out) {
     if (!c || !out || max_num <= min_num) return fail(F2V_EINVAL, "f2v_rand_index: bad argument");
     *out = c->rng.index(max_num, min_num);
+    return F2V_OK;
+}
+
+int f2v_rand_indices(f2v_handle c, uint32_t max_num, uint32_t min_num, uint64_t count, uint64_t keep, uint32_t *out) {
+    if (!c || max_num <= min_num || keep > count || (keep && !out)) return fail(F2V_EINVAL, "f2v_rand_indices: bad argument");
+    for (uint64_t k = 0; k < count; k++) {
+        const uint32_t r = c->rng.index(max_num, min_num);
+        if (k < keep) out[k] = r;
+    }
     return F2V_OK;
 }
 
@@ -412,7 +528,35 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
         int rc = flush_pending(c);
         if (rc != F2V_OK) return rc;
         HIPC(hipStreamSynchronize(c->stream));
+        if (value > (int64_t)kItemSlotMask) return fail(F2V_EINVAL, "hub_chunk out of range");
         c->chunk = (uint32_t)value;
+        c->chunk_auto = false;
+        drop_plans(c);
+        return F2V_OK;
+    }
+    if (!strcmp(name, "hub_chunk_for_batch")) {  // resolve the automatic chunk for this batch size now
+        if (value <= 0 || value > 0xFFFFFFFFll) return fail(F2V_EINVAL, "hub_chunk_for_batch: bad batch size");
+        HIPC(hipSetDevice(c->device));
+        int rc = flush_pending(c);
+        if (rc != F2V_OK) return rc;
+        HIPC(hipStreamSynchronize(c->stream));
+        const uint32_t ch = auto_chunk(c, (uint32_t)value);
+        if (ch != c->chunk) { c->chunk = ch; drop_plans(c); }
+        c->chunk_auto = true;
+        return F2V_OK;
+    }
+    if (!strcmp(name, "hub_fanin")) {
+        if (value < 0 || value == 1 || value > 0x7FFFFFFF) return fail(F2V_EINVAL, "hub_fanin must be 0 (one sequential pass) or >= 2");
+        HIPC(hipSetDevice(c->device));
+        int rc = flush_pending(c);
+        if (rc != F2V_OK) return rc;
+        HIPC(hipStreamSynchronize(c->stream));
+        c->fanin = (uint32_t)value;
+        drop_plans(c);
+        return F2V_OK;
+    }
+    if (!strcmp(name, "quarter_wave")) {
+        c->use_quarter = value != 0;
         return F2V_OK;
     }
     if (!strcmp(name, "waves_per_block")) {
@@ -427,6 +571,9 @@ int f2v_get_param(f2v_handle c, const char *name, int64_t *out) {
     if (!c || !name || !out) return fail(F2V_EINVAL, "f2v_get_param: null argument");
     if (!strcmp(name, "hub_chunk")) { *out = c->chunk; return F2V_OK; }
     if (!strcmp(name, "waves_per_block")) { *out = c->waves_per_block; return F2V_OK; }
+    if (!strcmp(name, "quarter_wave")) { *out = c->use_quarter ? 1 : 0; return F2V_OK; }
+    if (!strcmp(name, "hub_fanin")) { *out = c->fanin; return F2V_OK; }
+    if (!strcmp(name, "hub_chunk_auto")) { *out = c->chunk_auto ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "dim")) { *out = c->D; return F2V_OK; }
     if (!strcmp(name, "n")) { *out = c->n; return F2V_OK; }
     if (!strcmp(name, "nnz")) { *out = (int64_t)c->nnz; return F2V_OK; }
@@ -573,7 +720,18 @@ int f2v_train(f2v_handle c, int option, uint32_t iters, uint32_t batch, uint32_t
         HIPC(hipStreamSynchronize(c->stream));
         if ((rc = reserve_stage(c, std::min(batch, n))) != F2V_OK) return rc;
     }
-    if ((rc = build_hub_plan(c)) != F2V_OK) return rc;
+    if (c->chunk_auto) {
+        const uint32_t ch = auto_chunk(c, batch);
+        if (ch != c->chunk) {
+            if ((rc = flush_pending(c)) != F2V_OK) return rc;
+            HIPC(hipStreamSynchronize(c->stream));
+            c->chunk = ch;
+            drop_plans(c);
+        }
+    }
+    for (uint32_t b = 0; b < nb; b++)  // all launch plans up-front: one upload, no syncs inside the timed loop
+        (void)plan_for(c, b * batch, (uint32_t)std::min<uint64_t>((uint64_t)b * batch + batch, n), math == 7);
+    if ((rc = upload_plans(c)) != F2V_OK) return rc;
     // Sample ids do not depend on the embeddings: options 5/6 pre-draw every epoch's ids (as long
     // as that stays below 1 GiB); option 7 interleaves walk generation, so it goes epoch by epoch.
     const bool all_upfront = (math != 7) && (per_epoch * iters * 4ull <= (1ull << 30));

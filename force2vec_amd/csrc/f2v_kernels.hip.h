@@ -22,9 +22,10 @@
 // writes.  Rows of the CURRENT batch are only read from X (their pre-batch values), which is
 // exactly the reference's snapshot semantics for samples and in-batch neighbours.
 //
-// Hub rows (degree > chunk) are cut into chunks of `chunk` neighbours handled by separate
-// waves that leave partial sums in HBM; hub_finalize_kernel adds them in chunk order
-// (the GPU counterpart of option 11's nnz-balanced partition, sample/algorithms.cpp:2483-2523).
+// Load balance (the GPU counterpart of option 11's nnz-balanced partition,
+// sample/algorithms.cpp:2483-2523): the host cuts every minibatch into work ITEMS -- a whole
+// row, or one `chunk`-neighbour piece of a hub row (degree > chunk) -- sorted longest first.
+// Hub pieces leave partial sums in HBM; hub_finalize_kernel adds them, `fanin` at a time, in chunk order.
 #ifndef F2V_KERNELS_HIP_H_
 #define F2V_KERNELS_HIP_H_
 
@@ -33,39 +34,51 @@
 
 namespace f2v {
 
+// One unit of work: a whole row, or one chunk of a hub row's neighbour list.
+struct Item {
+    uint32_t row;    // source vertex
+    uint32_t nb;     // first index into nbr_ids
+    uint32_t cnt;    // neighbours in this item
+    uint32_t flags;  // kItem* bits | partial slot (low 28 bits)
+};
+constexpr uint32_t kItemPartial = 1u << 31;  // store the force sum to partials[slot] (hub chunk), not the new row
+constexpr uint32_t kItemFirst = 1u << 30;    // first chunk of its row (sigmoid: accumulates onto x_i)
+constexpr uint32_t kItemLast = 1u << 29;     // last chunk of its row: also takes the negative samples
+constexpr uint32_t kItemSlotMask = (1u << 28) - 1;
+
 struct StepArgs {
     float *X;                    // N x D embedding matrix (row-major, fp32)
     const uint32_t *rowptr;      // CSR row pointers [N+1]
     const uint32_t *nbr_ids;     // CSR colids, or the epoch's walk samples [5*N] (option 7)
     const float *stage_prev;     // new rows of the previous (pending) minibatch
     float *stage_cur;            // new rows of this minibatch
-    float *partials;             // hub chunk partial sums of this launch [n_extra x D]
+    float *partials;             // hub chunk partial sums of this launch [slots x D]
     const uint32_t *sample_ids;  // negative-sample vertex ids of this minibatch (device)
-    const uint2 *extras;         // (row, chunk) of each hub chunk item of this launch
+    const Item *items;           // this launch's work items, longest first
     const float *sm_table;       // 2048-entry sigmoid table
     uint32_t D;
     uint32_t batch_lo;           // first row of the minibatch (staging row 0)
-    uint32_t row_lo, n_rows;     // rows this launch computes
+    uint32_t n_items;
     uint32_t prev_lo, prev_rows; // pending minibatch to commit / redirect to
-    uint32_t n_extra;
     uint32_t ns;
     uint32_t bs_mode;
-    uint32_t chunk;              // hub chunk size (0 = never split)
-    uint32_t walk_mode;          // option 7: neighbours are nbr_ids[5*row .. 5*row+5)
     float lr;
 };
 
-struct HubRow {
-    uint32_t row, slot0, nchunks;
+// One node of a hub row's combine tree: add partial rows [in_slot, in_slot+n) in order.
+struct FinItem {
+    uint32_t in_slot, n;
+    uint32_t out;  // partial slot of the sum, or kFinToStage: it is the row's total -> stage the new row
+    uint32_t row;
 };
+constexpr uint32_t kFinToStage = 0xFFFFFFFFu;
 
 struct FinalizeArgs {
     const float *X;
-    const float *partials;  // same base as StepArgs::partials
+    float *partials;
     float *stage_cur;
-    const HubRow *hubs;     // slot0 relative to this launch's first slot
-    uint32_t slot_base;     // global slot of this launch's first hub chunk
-    uint32_t n_hubs;
+    const FinItem *items;
+    uint32_t n_items;
     uint32_t D;
     uint32_t batch_lo;
 };
@@ -240,6 +253,7 @@ __device__ __forceinline__ void process_list(const StepArgs &a, const uint32_t *
     }
 }
 
+// Generic layout (any D <= 512): one wavefront per work item.
 template <int OPT, int VEC, bool EXACT>
 __global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -254,35 +268,15 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
         load_row<VEC, EXACT>(a.stage_prev + (size_t)r * D, lane, D, t);
         store_row<VEC, EXACT>(a.X + (size_t)(a.prev_lo + r) * D, lane, D, t);
     }
+    if (w >= a.n_items) return;
 
-    // (2) this wave's item: a hub chunk, or a whole row
-    uint32_t row, nb, ne;
-    bool last_chunk = true, first_chunk = true, partial = false;
-    float *out;
-    if (w < a.n_extra) {
-        const uint2 e = a.extras[w];
-        row = e.x;
-        const uint32_t rp = a.rowptr[row], rpe = a.rowptr[row + 1];
-        nb = rp + e.y * a.chunk;
-        ne = (rpe - nb) > a.chunk ? nb + a.chunk : rpe;
-        last_chunk = (ne == rpe);
-        first_chunk = (e.y == 0);
-        partial = true;
-        out = a.partials + (size_t)w * D;
-    } else {
-        const uint32_t r = w - a.n_extra;
-        if (r >= a.n_rows) return;
-        row = a.row_lo + r;
-        if (a.walk_mode) {
-            nb = row * 5u;
-            ne = nb + 5u;
-        } else {
-            nb = a.rowptr[row];
-            ne = a.rowptr[row + 1];
-            if (a.chunk != 0 && (ne - nb) > a.chunk) return;  // hub row: its chunks are extra items
-        }
-        out = a.stage_cur + (size_t)(row - a.batch_lo) * D;
-    }
+    // (2) this wave's item
+    const Item it = a.items[w];
+    const uint32_t row = it.row;
+    const bool partial = (it.flags & kItemPartial) != 0;
+    const bool first_chunk = (it.flags & kItemFirst) != 0;
+    const bool last_chunk = (it.flags & kItemLast) != 0;
+    float *out = partial ? a.partials + (size_t)(it.flags & kItemSlotMask) * D : a.stage_cur + (size_t)(row - a.batch_lo) * D;
 
     float xi[VEC], Y[VEC];
     load_row<VEC, EXACT>(a.X + (size_t)row * D, lane, D, xi);
@@ -299,7 +293,7 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
         c0 = (double)(a.lr * degi);
     }
 
-    process_list<OPT, VEC, EXACT, false>(a, a.nbr_ids, nb, ne, lane, xi, Y, c0);
+    process_list<OPT, VEC, EXACT, false>(a, a.nbr_ids, it.nb, it.nb + it.cnt, lane, xi, Y, c0);
     if (last_chunk) {
         const uint32_t sbase = a.bs_mode ? (row - a.batch_lo) : 0u;
         process_list<OPT, VEC, EXACT, true>(a, a.sample_ids, sbase, sbase + a.ns, lane, xi, Y, c0);
@@ -314,29 +308,249 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
     store_row<VEC, EXACT>(out, lane, D, Y);
 }
 
-// Adds a hub row's chunk partials in chunk order and stages the row's new embedding.
+// ---- quarter-wave layout (D = 64*NB, NB in {1,2,4}) ---------------------------------------------
+// Four work items per wavefront, one per 16-lane DPP row.  Lane t of a quarter owns, in each
+// 64-dim block b, the four contiguous dims [64b + 4t, 64b + 4t + 4): every row is NB coalesced
+// 256-byte (16 lanes x dwordx4) loads, the 64-dim block sums are an in-lane pair tree plus the
+// four DPP row steps (xor 1, 2, 4, 8 -- no LDS crossbar, no SGPR hop), and the blocks are added
+// pairwise: the same canonical adjacent-pair tree as the generic layout, so results are
+// bit-identical.  Every VALU instruction now serves four (row, neighbour) pairs instead of one,
+// which takes the kernel from VALU-bound (14 fp64 + 20 fp32 ops per pair) to gather-bound.
+// Items arrive sorted by length, so the four quarters of a wave run almost equally long.
+__device__ __forceinline__ float row16_allreduce_tree(float v) {
+    v = v + dpp_mov<0xB1>(v);
+    v = v + dpp_mov<0x4E>(v);
+    v = v + dpp_mov<0x141>(v);
+    v = v + dpp_mov<0x140>(v);
+    return v;
+}
+
+template <int OPT, int NB, bool NEG>
+__device__ __forceinline__ void pair_update_q(const float (&xi)[NB][4], const float4 (&xj4)[NB], float (&Y)[NB][4],
+                                              float lr, double c0, const float *table) {
+    float xj[NB][4], bs[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        xj[b][0] = xj4[b].x; xj[b][1] = xj4[b].y; xj[b][2] = xj4[b].z; xj[b][3] = xj4[b].w;
+    }
+    if constexpr (OPT == 5) {
+        float diff[NB][4];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            float t[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                diff[b][v] = xi[b][v] - xj[b][v];
+                t[v] = diff[b][v] * diff[b][v];
+            }
+            bs[b] = row16_allreduce_tree((t[0] + t[1]) + (t[2] + t[3]));
+        }
+        float a;
+        if constexpr (NB == 1) a = bs[0];
+        else if constexpr (NB == 2) a = bs[0] + bs[1];
+        else a = (bs[0] + bs[1]) + (bs[2] + bs[3]);
+        float d1;
+        if constexpr (NEG)
+            d1 = (float)(2.0 / ((double)a * (1.0 + (double)a)));  // algorithms.cpp:622
+        else
+            d1 = (float)(-2.0 / (1.0 + (double)a));               // algorithms.cpp:608
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float f = clamp_ref(diff[b][v] * d1);
+                const float s = lr * f;
+                Y[b][v] = Y[b][v] + s;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            float t[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) t[v] = xi[b][v] * xj[b][v];
+            bs[b] = row16_allreduce_tree((t[0] + t[1]) + (t[2] + t[3]));
+        }
+        float a;
+        if constexpr (NB == 1) a = bs[0];
+        else if constexpr (NB == 2) a = bs[0] + bs[1];
+        else a = (bs[0] + bs[1]) + (bs[2] + bs[3]);
+        const float sm = fast_sm(table, a);
+        if constexpr (!NEG) {
+            const double coef = (1.0 - (double)sm) * c0;  // algorithms.cpp:867
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) Y[b][v] = (float)((double)xj[b][v] * coef + (double)Y[b][v]);
+        } else {
+            const float w = lr * sm;  // algorithms.cpp:907
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float p = w * xj[b][v];
+                    Y[b][v] = Y[b][v] - p;
+                }
+        }
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ const float *row_src(const StepArgs &a, uint32_t j) {
+    const uint32_t pj = j - a.prev_lo;
+    return (pj < a.prev_rows) ? a.stage_prev + (size_t)pj * (64u * NB) : a.X + (size_t)j * (64u * NB);
+}
+
+// One quarter's list of row ids; `cnt` is this quarter's length, `maxcnt` the wave's (uniform).
+// U rows per quarter (4U per wave) are in flight before the first interaction is evaluated; the
+// ids of the next group are fetched one group ahead.
+template <int OPT, int NB, bool NEG>
+__device__ __forceinline__ void qprocess(const StepArgs &a, const uint32_t *ids, uint32_t cnt, uint32_t maxcnt, uint32_t t,
+                                         const float (&xi)[NB][4], float (&Y)[NB][4], double c0) {
+    constexpr int U = 4;
+    uint32_t j[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) j[u] = ((uint32_t)u < cnt) ? ids[u] : 0u;
+    for (uint32_t g = 0; g < maxcnt; g += U) {
+        float4 xj[U][NB];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (g + u < cnt) {
+                const float *src = row_src<NB>(a, j[u]) + t * 4;
+#pragma unroll
+                for (int b = 0; b < NB; ++b) xj[u][b] = *reinterpret_cast<const float4 *>(src + 64 * b);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) j[u] = (g + U + u < cnt) ? ids[g + U + u] : 0u;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (g + u < cnt) pair_update_q<OPT, NB, NEG>(xi, xj[u], Y, a.lr, c0, a.sm_table);
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t wave_max_of_quarters(uint32_t v) {
+    const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), a1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t a2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), a3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    const uint32_t m0 = a0 > a1 ? a0 : a1, m1 = a2 > a3 ? a2 : a3;
+    return m0 > m1 ? m0 : m1;
+}
+
+template <int OPT, int NB>
+__global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
+    constexpr uint32_t D = 64u * NB;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t t = lane & 15u, q = lane >> 4;
+    const uint32_t wpb = blockDim.x >> 6;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + (threadIdx.x >> 6)));
+    const uint32_t total_q = gridDim.x * wpb * 4u;
+
+    // (1) commit the pending minibatch, one row per quarter (K5, algorithms.cpp:629-639)
+    for (uint32_t r = 4u * w + q; r < a.prev_rows; r += total_q) {
+        const float *src = a.stage_prev + (size_t)r * D + t * 4;
+        float *dst = a.X + (size_t)(a.prev_lo + r) * D + t * 4;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) *reinterpret_cast<float4 *>(dst + 64 * b) = *reinterpret_cast<const float4 *>(src + 64 * b);
+    }
+    if (4u * w >= a.n_items) return;
+
+    // (2) this quarter's item (quarters past the end of the list idle with cnt = 0)
+    const uint32_t idx = 4u * w + q;
+    const bool active = idx < a.n_items;
+    Item it;
+    if (active) it = a.items[idx];
+    else { it.row = 0; it.nb = 0; it.cnt = 0; it.flags = 0; }
+    const uint32_t row = it.row;
+    const bool partial = (it.flags & kItemPartial) != 0;
+    const bool first_chunk = (it.flags & kItemFirst) != 0;
+    const bool last_chunk = (it.flags & kItemLast) != 0;
+
+    float xi[NB][4], Y[NB][4];
+    {
+        const float *src = a.X + (size_t)row * D + t * 4;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const float4 v = *reinterpret_cast<const float4 *>(src + 64 * b);
+            xi[b][0] = v.x; xi[b][1] = v.y; xi[b][2] = v.z; xi[b][3] = v.w;
+        }
+    }
+    double c0 = 0.0;
+    if constexpr (OPT == 5) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) Y[b][v] = 0.0f;
+    } else {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) Y[b][v] = first_chunk ? xi[b][v] : 0.0f;
+        const uint32_t gdeg = a.rowptr[row + 1] - a.rowptr[row];
+        const float degi = (float)(1.0 / (double)(gdeg + 1u));  // algorithms.cpp:854
+        c0 = (double)(a.lr * degi);
+    }
+
+    qprocess<OPT, NB, false>(a, a.nbr_ids + it.nb, it.cnt, wave_max_of_quarters(it.cnt), t, xi, Y, c0);
+    {
+        const uint32_t scnt = (active && last_chunk) ? a.ns : 0u;
+        const uint32_t sbase = a.bs_mode ? (row - a.batch_lo) : 0u;
+        qprocess<OPT, NB, true>(a, a.sample_ids + sbase, scnt, wave_max_of_quarters(scnt), t, xi, Y, c0);
+    }
+
+    if (active) {
+        float *out = (partial ? a.partials + (size_t)(it.flags & kItemSlotMask) * D : a.stage_cur + (size_t)(row - a.batch_lo) * D) + t * 4;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            float4 v;
+            if (OPT == 5 && !partial)
+                v = make_float4(xi[b][0] + Y[b][0], xi[b][1] + Y[b][1], xi[b][2] + Y[b][2], xi[b][3] + Y[b][3]);  // algorithms.cpp:636
+            else
+                v = make_float4(Y[b][0], Y[b][1], Y[b][2], Y[b][3]);
+            *reinterpret_cast<float4 *>(out + 64 * b) = v;
+        }
+    }
+}
+
+// One level of the hub combine trees of a launch: every item adds up to `fanin` partial rows in
+// order (8 row loads in flight); the root of a row's tree stages the row's new embedding.
 template <int OPT, int VEC, bool EXACT>
 __global__ __launch_bounds__(256) void hub_finalize_kernel(const FinalizeArgs f) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-    if (w >= f.n_hubs) return;
-    const HubRow h = f.hubs[w];
+    if (w >= f.n_items) return;
+    const FinItem h = f.items[w];
     const uint32_t D = f.D;
-    const float *p = f.partials + (size_t)(h.slot0 - f.slot_base) * D;
-    float Y[VEC], P[VEC];
+    const float *p = f.partials + (size_t)h.in_slot * D;
+    float Y[VEC];
     load_row<VEC, EXACT>(p, lane, D, Y);
-    for (uint32_t c = 1; c < h.nchunks; ++c) {
-        load_row<VEC, EXACT>(p + (size_t)c * D, lane, D, P);
+    constexpr int U = 8;
+    for (uint32_t c = 1; c < h.n; c += U) {
+        float P[U][VEC];
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) Y[v] = Y[v] + P[v];
-    }
-    if constexpr (OPT == 5) {
-        float xi[VEC];
-        load_row<VEC, EXACT>(f.X + (size_t)h.row * D, lane, D, xi);
+        for (int u = 0; u < U; ++u) {
+            const uint32_t k = (c + u) < h.n ? (c + u) : (h.n - 1);
+            load_row<VEC, EXACT>(p + (size_t)k * D, lane, D, P[u]);
+        }
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) Y[v] = xi[v] + Y[v];
+        for (int u = 0; u < U; ++u) {
+            if (c + u < h.n) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) Y[v] = Y[v] + P[u][v];
+            }
+        }
     }
-    store_row<VEC, EXACT>(f.stage_cur + (size_t)(h.row - f.batch_lo) * D, lane, D, Y);
+    if (h.out == kFinToStage) {
+        if constexpr (OPT == 5) {
+            float xi[VEC];
+            load_row<VEC, EXACT>(f.X + (size_t)h.row * D, lane, D, xi);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) Y[v] = xi[v] + Y[v];
+        }
+        store_row<VEC, EXACT>(f.stage_cur + (size_t)(h.row - f.batch_lo) * D, lane, D, Y);
+    } else {
+        store_row<VEC, EXACT>(f.partials + (size_t)h.out * D, lane, D, Y);
+    }
 }
 
 // X[lo + r] = stage[r] for r < rows (commit without a following step)

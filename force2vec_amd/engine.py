@@ -67,6 +67,13 @@ class Engine:
         check(self._L.f2v_rand_index(self._h, max_num, min_num, C.byref(out)))
         return out.value
 
+    def draw_samples(self, max_num, count, keep=None):
+        """`count` randIndex(max_num, 0) draws from the handle's rand() stream; the first `keep` are returned."""
+        keep = count if keep is None else keep
+        out = np.empty(max(keep, 1), dtype=np.uint32)
+        check(self._L.f2v_rand_indices(self._h, max_num, 0, count, keep, _u32(out)))
+        return out[:keep]
+
     def set_param(self, name, value):
         check(self._L.f2v_set_param(self._h, name.encode(), int(value)))
 

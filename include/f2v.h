@@ -55,8 +55,11 @@ int f2v_init_embeddings(f2v_handle h, int kind);
 int f2v_set_embeddings(f2v_handle h, const float *x);
 int f2v_get_embeddings(f2v_handle h, float *x_out);
 
-/* Tunables: "hub_chunk" (neighbours per wave before a row is split; 0 = never split, the
- * reference's summation order for every row), "waves_per_block". */
+/* Tunables.  "hub_chunk": neighbours per work item before a row is split (0 = never split: the
+ * reference's summation order for every row; unset = chosen from the batch size by f2v_train, or
+ * by setting "hub_chunk_for_batch" = B); "hub_fanin": fan-in of the tree that adds a split row's
+ * partial sums (0 = one sequential pass); "quarter_wave": 0 selects the one-item-per-wavefront
+ * kernel for every D; "waves_per_block".  f2v_get_param also answers "dim", "n", "nnz". */
 int f2v_set_param(f2v_handle h, const char *name, int64_t value);
 int f2v_get_param(f2v_handle h, const char *name, int64_t *value_out);
 
@@ -91,6 +94,9 @@ int f2v_set_walks(f2v_handle h, const uint32_t *walks);
 int f2v_generate_walks(f2v_handle h, uint32_t *walks_out /* may be NULL */);
 /* randIndex(max,min) of sample/algorithms.cpp:55-58 on the handle's stream. */
 int f2v_rand_index(f2v_handle h, uint32_t max_num, uint32_t min_num, uint32_t *out);
+/* `count` consecutive randIndex(max,min) draws; the first `keep` (<= count) are stored in out.
+ * (One minibatch's sample loop, sample/algorithms.cpp:577-586; -bs 1 draws ns*BATCH, :686.) */
+int f2v_rand_indices(f2v_handle h, uint32_t max_num, uint32_t min_num, uint64_t count, uint64_t keep, uint32_t *out);
 
 /* Multi-GPU exchange: device address of the staged rows of the pending minibatch (row r of
  * the batch at float offset (r-batch_lo)*dim), the number of rows it can hold, and a host

@@ -20,8 +20,10 @@
  *       1,2,4,8,16,32).  The HIP kernels are bit-exact against this order.
  * and, orthogonally, hub chunking (chunk > 0): a row with more than `chunk` neighbours
  * is cut into chunks of `chunk` neighbours; each chunk accumulates from zero (the last
- * chunk also takes the negative samples) and the chunk partials are added in chunk
- * order.  chunk == 0 is the reference's single sequential accumulation.
+ * chunk also takes the negative samples) and the chunk partials are combined by a
+ * `fanin`-ary tree: consecutive groups of `fanin` partials are added sequentially, level
+ * by level, until one is left (fanin == 0: one sequential pass over all partials).
+ * chunk == 0 is the reference's single sequential accumulation.
  *
  * Build: gcc -O2 -ffp-contract=off -fPIC -shared (NO -ffast-math).  See oracle/Makefile.
  *
@@ -266,6 +268,27 @@ static float reduce_terms(float *t, uint32_t D, int order) {
     return t[0];
 }
 
+/* Hub combine fan-in (see the header); set through orc_set_fanin, default 32. */
+static uint32_t g_fanin = 32;
+void orc_set_fanin(uint32_t fanin) { g_fanin = fanin; }
+
+/* parts: n partial vectors of D floats, contiguous; combined in place into parts[0..D). */
+static void combine_partials(float *parts, uint32_t n, uint32_t D) {
+    uint32_t G = g_fanin ? g_fanin : n;
+    if (G < 2) G = 2;
+    while (n > 1) {
+        uint32_t nout = (n + G - 1) / G;
+        for (uint32_t o = 0; o < nout; o++) {
+            uint32_t lo = o * G, hi = lo + G < n ? lo + G : n;
+            float *acc = parts + (size_t)o * D; /* o <= lo: writing group o never clobbers unread input */
+            if (o != lo) memcpy(acc, parts + (size_t)lo * D, D * sizeof(float));
+            for (uint32_t k = lo + 1; k < hi; k++)
+                for (uint32_t d = 0; d < D; d++) acc[d] = acc[d] + parts[(size_t)k * D + d];
+        }
+        n = nout;
+    }
+}
+
 /* ------------------------------------------------------------------------------------
  * One row of one minibatch.  X is the embedding matrix BEFORE the minibatch (Jacobi
  * inside a batch), S[k] points at the k-th negative-sample row as it was before the
@@ -299,22 +322,21 @@ static void row_tdist(const float *X, uint32_t D, uint32_t i, const uint32_t *nb
                       const float *const *S, uint32_t ns, float lr, int order, uint32_t chunk,
                       float *out) {
     const float *xi = X + (size_t)i * D;
-    float Y[ORC_MAXDIM], P[ORC_MAXDIM];
     uint32_t nchunks = (chunk > 0 && deg > chunk) ? (deg + chunk - 1) / chunk : 1;
+    float *parts = (float *)malloc((size_t)nchunks * D * sizeof(float));
     for (uint32_t c = 0; c < nchunks; c++) {
         uint32_t lo = (nchunks == 1) ? 0 : c * chunk;
         uint32_t hi = (nchunks == 1) ? deg : (lo + chunk < deg ? lo + chunk : deg);
+        float *P = parts + (size_t)c * D;
         for (uint32_t d = 0; d < D; d++) P[d] = 0.0f;
         for (uint32_t k = lo; k < hi; k++)
             tdist_accumulate(xi, X + (size_t)nbrs[k] * D, D, lr, order, 0, P);
         if (c == nchunks - 1)
             for (uint32_t s = 0; s < ns; s++) tdist_accumulate(xi, S[s], D, lr, order, 1, P);
-        if (c == 0)
-            memcpy(Y, P, D * sizeof(float));
-        else
-            for (uint32_t d = 0; d < D; d++) Y[d] = Y[d] + P[d];
     }
-    for (uint32_t d = 0; d < D; d++) out[d] = xi[d] + Y[d]; /* algorithms.cpp:636 */
+    combine_partials(parts, nchunks, D);
+    for (uint32_t d = 0; d < D; d++) out[d] = xi[d] + parts[d]; /* algorithms.cpp:636 */
+    free(parts);
 }
 
 /* options 6/7 row: sample/algorithms.cpp:833-921 (6), 1142-1193 (7).
@@ -323,13 +345,15 @@ static void row_sigmoid(const float *X, uint32_t D, uint32_t i, const uint32_t *
                         uint32_t graph_deg, const float *const *S, uint32_t ns, float lr,
                         const float *table, int order, uint32_t chunk, float *out) {
     const float *xi = X + (size_t)i * D;
-    float Y[ORC_MAXDIM], P[ORC_MAXDIM], t[ORC_MAXDIM];
+    float t[ORC_MAXDIM];
     float degi = (float)(1.0 / (double)(graph_deg + 1u)); /* algorithms.cpp:854 */
     double c0 = (double)(lr * degi);
     uint32_t nchunks = (chunk > 0 && deg > chunk) ? (deg + chunk - 1) / chunk : 1;
+    float *parts = (float *)malloc((size_t)nchunks * D * sizeof(float));
     for (uint32_t c = 0; c < nchunks; c++) {
         uint32_t lo = (nchunks == 1) ? 0 : c * chunk;
         uint32_t hi = (nchunks == 1) ? deg : (lo + chunk < deg ? lo + chunk : deg);
+        float *P = parts + (size_t)c * D;
         /* chunk 0 starts from x_i (the reference's copy-in); later chunks from zero */
         for (uint32_t d = 0; d < D; d++) P[d] = (c == 0) ? xi[d] : 0.0f;
         for (uint32_t k = lo; k < hi; k++) {
@@ -353,12 +377,10 @@ static void row_sigmoid(const float *X, uint32_t D, uint32_t i, const uint32_t *
                 }
             }
         }
-        if (c == 0)
-            memcpy(Y, P, D * sizeof(float));
-        else
-            for (uint32_t d = 0; d < D; d++) Y[d] = Y[d] + P[d];
     }
-    memcpy(out, Y, D * sizeof(float)); /* algorithms.cpp:918 */
+    combine_partials(parts, nchunks, D);
+    memcpy(out, parts, D * sizeof(float)); /* algorithms.cpp:918 */
+    free(parts);
 }
 
 /* ------------------------------------------------------------------------------------

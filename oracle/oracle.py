@@ -45,6 +45,7 @@ def lib():
         L.orc_sm_table_as_compiled.restype = C.c_int
         L.orc_sm_table_as_compiled.argtypes = [f32p]
         L.orc_set_sm_table.argtypes = [f32p]
+        L.orc_set_fanin.argtypes = [C.c_uint32]
         L.orc_fast_sm.restype = C.c_float
         L.orc_fast_sm.argtypes = [f32p, C.c_float]
         L.orc_minibatch.restype = C.c_int
@@ -133,6 +134,11 @@ def set_sm_table(table=None):
         table = np.ascontiguousarray(table, dtype=np.float32)
         assert table.shape == (2048,)
         lib().orc_set_sm_table(_f32(table))
+
+
+def set_fanin(fanin=32):
+    """Hub combine fan-in of the chunked order (0 = one sequential pass); the engine's "hub_fanin"."""
+    lib().orc_set_fanin(fanin)
 
 
 def minibatch(option, rowptr, colids, X, lo, hi, sample_ids, ns, lr, bs_mode=0, walks=None,

@@ -108,6 +108,32 @@ def test_minibatch_steps_bit_exact(F, option, dim, bs, chunk, n, batch):
     eng.close()
 
 
+@pytest.mark.parametrize("option", [5, 6])
+@pytest.mark.parametrize("fanin", [0, 2, 3, 32])
+def test_hub_combine_tree(F, option, fanin):
+    """Hub rows of 90 and 300 neighbours cut into 2-neighbour chunks: up to 8 levels of the fan-in tree."""
+    n, dim, batch = 320, 128, 128
+    rowptr, colids = random_graph(n, 4, seed=21, hubs=((1, 90), (200, 300)))
+    rng = np.random.default_rng(2)
+    X0 = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    eng = F.Engine(rowptr, colids, dim)
+    eng.set_param("hub_chunk", 2)
+    eng.set_param("hub_fanin", fanin)
+    O.set_fanin(fanin)
+    try:
+        eng.set_embeddings(X0)
+        Xo = X0.copy()
+        for lo in range(0, n, batch):
+            hi = min(lo + batch, n)
+            ids = rng.integers(0, n - 1, 5).astype(np.uint32)
+            eng.minibatch_step(option, lo, hi, ids, 5, 0.02)
+            O.minibatch(option, rowptr, colids, Xo, lo, hi, ids, 5, 0.02, order=O.ORDER_TREE, chunk=2)
+        assert np.array_equal(eng.get_embeddings(), Xo)
+    finally:
+        O.set_fanin(32)
+        eng.close()
+
+
 def test_sharded_rows_and_stage_exchange(F):
     """The multi-GPU unit: two engines each compute half of every minibatch and exchange staged rows."""
     n, dim, batch = 260, 128, 100
@@ -166,6 +192,25 @@ def test_train_bit_exact_vs_oracle_and_close_to_reference(F, graph, option, iter
     algo.engine.close()
 
 
+@pytest.mark.parametrize("option,dim", [(5, 64), (5, 128), (5, 256), (6, 128), (6, 256), (7, 64)])
+def test_quarter_wave_and_generic_layouts_agree(F, option, dim):
+    """The quarter-wave kernel (4 items per wavefront) and the generic one (1 item per wavefront)
+    implement the same canonical reduction tree: identical bits."""
+    rowptr, colids = random_graph(500, 10, seed=3, hubs=((2, 300), (400, 77)))
+    res = []
+    for q in (1, 0):
+        a = F.algorithms((rowptr, colids), dim=dim)
+        a.engine.set_param("quarter_wave", q)
+        a.engine.set_param("hub_chunk", 32)
+        a.srand(1)
+        a._run(option, 0, 3, 128, 5, 0.02, write=False)
+        res.append(a.nCoordinates)
+        a.engine.close()
+    assert np.array_equal(res[0], res[1])
+    want = O.train(option, rowptr, colids, dim, 3, 128, order=O.ORDER_TREE, chunk=32)
+    assert np.array_equal(res[0], want)
+
+
 def test_options_8_to_11_alias_the_same_maths(F):
     rowptr, colids = F.read_mtx(golden_graph_path("karate.mtx"))
     res = {}
@@ -191,7 +236,9 @@ def test_cli_drop_in(F, tmp_path):
     assert "Algo:Force2Vec:t-distribution with negative sampling\tInit:RAND\tIteration:10" in open(out + "Results.txt").read()
     got = O.read_embd(path)
     rowptr, colids = O.read_mtx(golden_graph_path("cora.mtx"))
-    want = O.train(5, rowptr, colids, 128, 10, 256, order=O.ORDER_TREE, chunk=512)
+    probe = F.Engine(rowptr, colids, 128)
+    want = O.train(5, rowptr, colids, 128, 10, 256, order=O.ORDER_TREE, chunk=probe.get_param("hub_chunk"))
+    probe.close()
     wtxt = str(tmp_path / "want.embd")
     O.write_embd(wtxt, want)
     assert open(path, "rb").read() == open(wtxt, "rb").read()      # same floats -> same text
