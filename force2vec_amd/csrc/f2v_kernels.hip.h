@@ -1,18 +1,23 @@
 // f2v_kernels.hip.h -- the HIP/CDNA4 (gfx950) kernels of the Force2Vec hot path.
 //
-// Work decomposition: ONE 64-lane wavefront per source vertex (row) of the minibatch.
-// Lane l owns the VEC contiguous dimensions [l*VEC, l*VEC+VEC) of every D-dim row
-// (D <= 64*VEC; D = 128 -> VEC = 2: one 512-byte fully coalesced row per wave-load), so
+// Work decomposition: a wavefront (or, in the quarter-wave layout, a 16-lane DPP row) owns one
+// source vertex (row) of the minibatch for the whole of its neighbour list:
 //   * x_i and the row's force accumulator Y_i live in registers for the whole row,
-//   * each CSR neighbour / negative sample is one coalesced row gather,
-//   * the squared distance (t-distribution, option 5) or dot product (sigmoid, options
-//     6/7) is an in-lane adjacent-pair tree followed by a lane-xor butterfly
-//     (1,2,4,8 via DPP, 16 via ds_swizzle, 32 via two v_readlane): the canonical balanced
-//     adjacent-pair tree over next_pow2(D) terms that oracle/f2v_oracle.c::ORC_ORDER_TREE
-//     restates, so the kernels are bit-exact against the oracle,
+//   * each CSR neighbour / negative sample is one coalesced row gather from HBM,
+//   * the squared distance (t-distribution, option 5) or dot product (sigmoid, options 6/7)
+//     is reduced in ONE canonical order -- the balanced adjacent-pair binary tree over
+//     next_pow2(D) zero-padded terms -- built from an in-lane pair tree and DPP lane-xor
+//     steps; the test oracle restates that order on the CPU, so the kernels are checked
+//     bit for bit,
 //   * the fp64 scalars d1 / coef of the reference (sample/algorithms.cpp:608,622,867) are
-//     computed redundantly per lane in fp64, the clamp keeps the compiled reference's
-//     NaN -> -5 rule, and mul/add are NOT contracted (-ffp-contract=off).
+//     computed per lane in fp64, the clamp keeps the compiled reference's NaN -> -5 rule, and
+//     mul/add are NOT contracted (-ffp-contract=off).
+// Two layouts share those semantics:
+//   step_kernel  <OPT,VEC,EXACT>  any D <= 512: one item per wavefront, lane l owns dims
+//                                 [l*VEC, l*VEC+VEC); butterfly = DPP xor 1,2,4,8, ds_swizzle 16,
+//                                 v_readlane 32.
+//   qstep_kernel <OPT,NB>         D = 64*NB (64/128/256): FOUR items per wavefront, one per DPP
+//                                 row; every VALU instruction serves four (row, neighbour) pairs.
 //
 // Minibatch sequencing (Jacobi inside a batch, Gauss-Seidel across batches,
 // sample/algorithms.cpp:588-639) without a second launch per batch: the new rows of batch b

@@ -87,8 +87,9 @@ class NcclStageComm:
 class ShardedTrainer:
     """AlgoForce2Vec* over `world` engines: same epochs, minibatches and rand() order as f2v_train."""
 
-    def __init__(self, engine, rank, world, comm):
+    def __init__(self, engine, rank, world, comm, exchange_when_single=False):
         self.engine, self.rank, self.world, self.comm = engine, rank, world, comm
+        self.exchange_when_single = exchange_when_single  # self-test of the exchange path on one rank
 
     def train(self, option, iters, batch, ns=5, lr=0.02, bs_mode=0):
         e = self.engine
@@ -111,6 +112,6 @@ class ShardedTrainer:
                 ids = e.draw_samples(maxv, ndraw, min(keep, ndraw))
                 _, my_lo, my_hi = shard_bounds(lo, hi, self.rank, self.world)
                 e.minibatch_step(option, lo, hi, ids, ns, lr, bs_mode, row_lo=my_lo, row_hi=my_hi)
-                if self.world > 1:
+                if self.world > 1 or self.exchange_when_single:
                     self.comm.exchange(e, lo, hi)
         e.flush()

@@ -237,6 +237,7 @@ def test_cli_drop_in(F, tmp_path):
     got = O.read_embd(path)
     rowptr, colids = O.read_mtx(golden_graph_path("cora.mtx"))
     probe = F.Engine(rowptr, colids, 128)
+    probe.set_param("hub_chunk_for_batch", 256)  # the automatic choice f2v_train makes for -batch 256
     want = O.train(5, rowptr, colids, 128, 10, 256, order=O.ORDER_TREE, chunk=probe.get_param("hub_chunk"))
     probe.close()
     wtxt = str(tmp_path / "want.embd")

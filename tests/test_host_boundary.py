@@ -1,0 +1,140 @@
+"""CPU tests of the host side of the drop-in boundary (no GPU): the C ABI surface, the libc
+rand() restatement, MatrixMarket ingest, the .embd writer and naming, the CLI's argument
+behaviour.  libf2v.so must load without a GPU; compute entry points must refuse to run."""
+import ctypes as C
+import gzip
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, ROOT, golden_graph_path
+from oracle import oracle as O
+
+import force2vec_amd as F
+from force2vec_amd import _lib
+
+
+def test_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "f2v.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(f2v_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    L = C.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert b"gfx950" in _lib.lib().f2v_version()
+
+
+def test_no_cpu_fallback():
+    rp, ci = F.read_mtx(golden_graph_path("karate.mtx"))
+    try:
+        e = F.Engine(rp, ci, 16)
+    except _lib.F2VError as ex:  # no GPU here: the product refuses, loudly
+        assert ex.code == _lib.F2V_ENODEV and "no CPU fallback" in str(ex)
+    else:
+        e.close()  # on a GPU box the engine simply exists
+    src = ""
+    for root, _, files in os.walk(os.path.join(ROOT, "force2vec_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
+                src += open(os.path.join(root, f)).read()
+    # the product never imports, links or loads the oracle
+    assert not re.search(r"^\s*(import|from)\s+oracle\b", src, flags=re.M) and "liboracle" not in src
+
+
+def test_rng_matches_libc_and_oracle(manifest):
+    L = _lib.lib()
+    libc = C.CDLL("libc.so.6")
+    for seed in (1, 7, 0, 4242424242):
+        g = L.f2v_rng_create(seed)
+        libc.srand(seed)
+        o = O.Rng(seed)
+        for _ in range(3000):
+            v = L.f2v_rng_next(g)
+            assert v == libc.rand() == o.rand()
+        L.f2v_rng_destroy(g)
+    g = L.f2v_rng_create(1)
+    assert [L.f2v_rng_next(g) for _ in range(16)] == manifest["rand_after_srand1"]
+    L.f2v_rng_destroy(g)
+
+
+def test_sigmoid_table_is_the_source_level_one():
+    assert np.array_equal(F.sm_table(), O.sm_table())
+
+
+@pytest.mark.parametrize("g", ["karate.mtx", "cora.mtx", "citeseer.mtx"])
+def test_read_mtx_matches_oracle_reader(g):
+    rp, ci = F.read_mtx(golden_graph_path(g))
+    rp2, ci2 = O.read_mtx(golden_graph_path(g))
+    assert np.array_equal(rp, rp2) and np.array_equal(ci, ci2)
+    if g == "cora.mtx":  # N=2708, nnz=10858 (duplicates kept, no self-loops)
+        assert len(rp) - 1 == 2708 and len(ci) == 10858
+    for i in range(len(rp) - 1):
+        assert np.all(np.diff(ci[rp[i]:rp[i + 1]].astype(np.int64)) >= 0)
+
+
+def test_read_mtx_edge_cases(tmp_path):
+    # symmetric: mirrored, self-loop dropped, duplicate kept, isolated vertex 5, comment lines, values ignored
+    p = tmp_path / "s.mtx"
+    p.write_text("%%MatrixMarket matrix coordinate real symmetric\n% a comment\n5 5 5\n2 1 0.5\n3 1 2\n3 3 9\n2 1 7\n4 2 1\n")
+    rp, ci = F.read_mtx(str(p))
+    assert rp.tolist() == [0, 3, 6, 7, 8, 8] and ci.tolist() == [1, 1, 2, 0, 0, 3, 0, 1]
+    rp2, ci2 = O.read_mtx(str(p))
+    assert np.array_equal(rp, rp2) and np.array_equal(ci, ci2)
+    # general: kept as directed, diagonal kept (sample/IO.h:122-134 only drops it for symmetric files)
+    p = tmp_path / "g.mtx"
+    p.write_text("%%MatrixMarket matrix coordinate pattern general\n3 3 4\n1 2\n2 2\n3 1\n1 3\n")
+    rp, ci = F.read_mtx(str(p))
+    assert rp.tolist() == [0, 2, 3, 4] and ci.tolist() == [1, 2, 1, 0]
+    rp2, ci2 = O.read_mtx(str(p))
+    assert np.array_equal(rp, rp2) and np.array_equal(ci, ci2)
+    with pytest.raises(_lib.F2VError):
+        F.read_mtx(str(tmp_path / "missing.mtx"))
+    p = tmp_path / "bad.mtx"
+    p.write_text("%%MatrixMarket matrix coordinate pattern general\n3 3 1\n1 9\n")
+    with pytest.raises(_lib.F2VError):
+        F.read_mtx(str(p))
+
+
+def test_write_embd_reproduces_reference_text(tmp_path, manifest):
+    for case in manifest["cases"]:
+        if "file" not in case:
+            continue
+        with gzip.open(os.path.join(GOLD, case["file"]), "rb") as f:
+            txt = f.read()
+        ref = tmp_path / "ref.embd"
+        ref.write_bytes(txt)
+        X = O.read_embd(str(ref))
+        out = tmp_path / "out.embd"
+        F.write_embd(str(out), X)
+        assert out.read_bytes() == txt, case["name"]
+    X = np.array([[0.0, -0.0, 1e-30, -1e30, 123456.7, 1234567.0, 0.1, np.float32(1 / 3)]], dtype=np.float32)
+    F.write_embd(str(tmp_path / "a.embd"), X)
+    O.write_embd(str(tmp_path / "b.embd"), X)
+    assert (tmp_path / "a.embd").read_bytes() == (tmp_path / "b.embd").read_bytes()
+
+
+def test_output_names_match_reference(manifest):
+    for case in manifest["cases"]:
+        got = F.output_name("/some/dir/" + case["graph"], "/out/", case["option"], case["bs"], case["batch"], case["dim"], case["iters"], case["ns"])
+        assert got == "/out/" + case["embd_name"]
+    assert F.output_name("g.mtx", "", 11, 0, 256, 128, 10, 5) == "g.mtxF2VNSLB_AVXZ256D128IT10NS5.embd"
+    assert F.output_name("g.mtx", "", 11, 0, 256, 64, 10, 5) == "g.mtxF2VNSLB_AVXZ64256D64IT10NS5.embd"
+    with pytest.raises(_lib.F2VError):
+        F.output_name("g.mtx", "", 3, 0, 256, 64, 10, 5)
+
+
+def test_cli_argument_behaviour(tmp_path):
+    exe = os.path.join(ROOT, "bin", "Force2Vec")
+    r = subprocess.run([exe, "-h"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Usage of Force2Vec tool" in r.stdout and "-nsamples" in r.stdout
+    r = subprocess.run([exe, "-iter", "3"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Valid input file needed" in r.stdout
+    r = subprocess.run([exe, "-input", golden_graph_path("karate.mtx"), "-option", "3"], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 1 and "out of scope" in r.stdout
+    r = subprocess.run([exe, "-input", str(tmp_path / "nope.mtx")], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 2 and "cannot open" in r.stderr
