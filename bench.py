@@ -78,23 +78,31 @@ def cpu_baseline(args):
             src, dst = edges_from_csr(rowptr, colids)
             write_mtx_symmetric(mtx, n, src, dst)
 
-            def run(iters):
-                out = run_ref(O, mtx, td, option, iters, args, cores, avx512)
+            def run(iters, threads):
+                out = run_ref(O, mtx, td, option, iters, args, threads, avx512)
                 for line in out.splitlines():
                     if "Wall time required" in line:
                         return float(line.split(":")[-1].split()[0])
                 raise RuntimeError("reference output not understood:\n" + out)
 
-            t0 = run(0)
-            k = args.cpu_iters
-            tk = run(k)
-            # aim for >= ~10 s of CPU work
-            if tk - t0 < 5.0:
-                k2 = int(min(400, max(k + 1, k * 10.0 / max(tk - t0, 1e-3))))
-                tk, k = run(k2), k2
+            # the reference does not scale to every core count on every box: a short scan picks the
+            # thread count that serves it best, the long run below is what is reported
+            cands = sorted({c for c in (8, 16, 32, 48, 64, 96, 128, cores) if c <= cores})
+            best, best_rate = cores, 0.0
+            t0s = {}
+            for th in cands:
+                t0s[th] = run(0, th)
+                rate = 3.0 / max(run(3, th) - t0s[th], 1e-6)
+                if rate > best_rate:
+                    best, best_rate = th, rate
+            threads = best
+            t0 = t0s[threads]
+            k = int(min(2000, max(args.cpu_iters, 12.0 * best_rate)))  # about 12 s of CPU work
+            tk = run(k, threads)
         val = nnz * k / max(tk - t0, 1e-9)
-        return {"value": val, "unit": "edges/s", "cores": cores, "kind": "reference",
-                "sample": "%s; oracle/_ref option %d%s, %d epochs in %.2fs, -threads %d" % (sample, option, " (AVX512 build)" if avx512 else " (scalar build)", k, tk - t0, cores)}
+        return {"value": val, "unit": "edges/s", "cores": threads, "kind": "reference",
+                "sample": "%s; oracle/_ref option %d%s, %d epochs in %.2fs, -threads %d (best of %s on a %d-core host)"
+                          % (sample, option, " (AVX512 build)" if avx512 else " (scalar build)", k, tk - t0, threads, cands, cores)}
     # port: single-thread oracle, a few epochs
     X = O.Rng(1).init_embeddings(n, args.dim, 0)
     t0 = time.time()
@@ -212,7 +220,7 @@ def main():
             except Exception:
                 pass
         res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": traffic, "kernel": "step_kernel<5,2,true>", "algorithmic_bytes_per_launch": per_launch,
+                           "traffic": traffic, "kernel": "f2v::qstep_kernel<%d, %d>" % (5 if args.option in (5, 8, 11) else 6, args.dim // 64), "algorithmic_bytes_per_launch": per_launch,
                            "avg_launch_us": t_launch * 1e6, "launches": st["step_launches"]}
     if rank == 0 and world == 1:
         extra = {}

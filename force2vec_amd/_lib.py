@@ -55,6 +55,7 @@ SIGNATURES = {
     "f2v_rng_destroy": (None, [C.c_void_p]),
     "f2v_rng_next": (C.c_int, [C.c_void_p]),
     "f2v_sm_table": (C.c_int, [f32p]),
+    "f2v_test_gather_calibration": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32]),
     "f2v_test_wave_reduce": (C.c_int, [C.c_int, f32p, C.c_uint32, C.c_uint32, f32p]),
 }
 

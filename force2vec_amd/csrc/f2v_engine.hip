@@ -796,6 +796,34 @@ int f2v_train(f2v_handle c, int option, uint32_t iters, uint32_t batch, uint32_t
     return F2V_OK;
 }
 
+// PMC calibration hook: gathers `rows` distinct rows of 128 floats (a random permutation, so every
+// 512-byte row is fetched exactly once) with the step kernel's access pattern; `reps` launches.
+// Known HBM read volume per launch: rows * 512 bytes (+ 4 bytes per row of ids).
+int f2v_test_gather_calibration(int device, uint32_t rows, uint32_t reps) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(F2V_ENODEV, "no HIP device visible");
+    if (rows < 4) return fail(F2V_EINVAL, "rows");
+    HIPC(hipSetDevice(device));
+    float *d_t = nullptr, *d_o = nullptr;
+    uint32_t *d_i = nullptr;
+    HIPC(hipMalloc((void **)&d_t, (size_t)rows * 128 * sizeof(float)));
+    HIPC(hipMalloc((void **)&d_i, (size_t)rows * sizeof(uint32_t)));
+    HIPC(hipMalloc((void **)&d_o, 64));
+    HIPC(hipMemset(d_t, 0, (size_t)rows * 128 * sizeof(float)));
+    std::vector<uint32_t> perm(rows);
+    for (uint32_t i = 0; i < rows; i++) perm[i] = i;
+    Rand g;
+    g.seed(7);
+    for (uint32_t i = rows - 1; i > 0; i--) std::swap(perm[i], perm[(uint32_t)(((uint64_t)g.next() * 2147483648ull + (uint64_t)g.next()) % (i + 1))]);
+    HIPC(hipMemcpy(d_i, perm.data(), (size_t)rows * sizeof(uint32_t), hipMemcpyHostToDevice));
+    for (uint32_t r = 0; r < reps; r++)
+        hipLaunchKernelGGL((gather_calibration_kernel<2>), dim3(4096), dim3(256), 0, 0, d_t, d_i, rows, d_o);
+    HIPC(hipGetLastError());
+    HIPC(hipDeviceSynchronize());
+    (void)hipFree(d_t); (void)hipFree(d_i); (void)hipFree(d_o);
+    return F2V_OK;
+}
+
 int f2v_test_wave_reduce(int device, const float *in, uint32_t rows, uint32_t width, float *out) {
     if (!in || !out || width == 0 || width > 512) return fail(F2V_EINVAL, "f2v_test_wave_reduce: bad argument");
     int ndev = 0;

@@ -150,6 +150,9 @@ int f2v_sm_table(float *table_out /* 2048 */);
 /* ---- self-test hooks (used by tests/ only) ---------------------------------------------- */
 /* Runs the wavefront tree reduction on `rows` rows of `width` (<=512) floats; out[r] = sum. */
 int f2v_test_wave_reduce(int device, const float *in, uint32_t rows, uint32_t width, float *out);
+/* PMC calibration: `reps` launches that each gather `rows` distinct 512-byte rows exactly once with
+ * the step kernel's access pattern (known HBM read volume rows*516 bytes per launch). */
+int f2v_test_gather_calibration(int device, uint32_t rows, uint32_t reps);
 
 #ifdef __cplusplus
 }
