@@ -46,6 +46,7 @@ CASES = [
     ("cora.mtx", 5, 1, 256, 128, 0, False),
     ("cora.mtx", 5, 10, 256, 128, 0, True),      # BASELINE config 2 (short)
     ("cora.mtx", 5, 100, 256, 128, 0, False),
+    ("cora.mtx", 5, 1200, 256, 128, 0, False),   # the F1 gate's run (SURVEY md5 970dd1ab...)
     ("cora.mtx", 5, 5, 256, 64, 1, False),
     ("cora.mtx", 5, 10, 384, 128, 0, False),     # CLI default batch
     ("cora.mtx", 6, 10, 256, 128, 0, True),
@@ -74,6 +75,13 @@ def main():
                 with gzip.GzipFile(os.path.join(GOLD, name + ".embd.gz"), "wb", mtime=0) as f:
                     f.write(txt)
                 entry["file"] = name + ".embd.gz"
+            if (g, option, iters, batch, dim, bs) == ("cora.mtx", 5, 1200, 256, 128, 0):
+                # node-classification F1 of the REFERENCE's embedding under the seeded harness (tests/f1_harness.py)
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import f1_harness as H
+                labels = H.load_labels(os.path.join(REF_INPUT, "cora.nodes.labels"), 2708)
+                f1 = H.f1_scores(O.read_embd(path), labels)
+                manifest["f1_reference_cora_opt5_it1200_B256_D128"] = {"%.2f" % k: {"micro": v[0], "macro": v[1]} for k, v in f1.items()}
             manifest["cases"].append(entry)
             print(name, entry["md5"])
     # the graphs themselves are the reference's test data (inputs): keep the two tiny ones

@@ -212,6 +212,14 @@ def read_embd(path):
     return X
 
 
+def read_embd_roundtrip(X):
+    """X as a reader of the 6-significant-digit .embd text would see it."""
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".embd") as f:
+        write_embd(f.name, X)
+        return read_embd(f.name)
+
+
 # ---------------------------------------------------------------------------------------
 # The genuine reference binary (oracle/_ref), when present
 # ---------------------------------------------------------------------------------------

@@ -276,3 +276,23 @@ def test_full_size_sampled_rows(F):
         outside[lo:hi] = False
         assert np.array_equal(after[outside], before[outside])
     eng.close()
+
+
+def test_cora_f1_within_half_point_of_reference(F, manifest):
+    """BASELINE north_star gate: node-classification F1 on Cora within +-0.5 of the reference.  Option 5,
+    D=128, batch 256, 1200 epochs from srand(1) on the GPU, scored with the seeded restatement of
+    performancescores/runnodeclassclust.py on the same 10 splits per train fraction as the reference's own
+    embedding (its F1 table is committed in the manifest, generated from oracle/_ref's output)."""
+    import f1_harness as H
+    rowptr, colids = F.read_mtx(golden_graph_path("cora.mtx"))
+    algo = F.algorithms((rowptr, colids), dim=128)
+    algo.srand(1)
+    algo._run(5, 0, 1200, 256, 5, 0.02, write=False)
+    labels = H.load_labels(os.path.join(GOLD, "cora.nodes.labels"), len(rowptr) - 1)
+    got = H.f1_scores(algo.nCoordinates, labels)
+    ref = manifest["f1_reference_cora_opt5_it1200_B256_D128"]
+    for tf, (mic, mac) in got.items():
+        r = ref["%.2f" % tf]
+        assert abs(mic - r["micro"]) <= 0.5, (tf, mic, r["micro"])
+        assert abs(mac - r["macro"]) <= 0.75, (tf, mac, r["macro"])
+    algo.engine.close()
