@@ -30,12 +30,27 @@ struct CSRGraph {  // CSR<INDEXTYPE, VALUETYPE> of sample/CSR.h:89-96 (values ar
     CSRGraph &operator=(const CSRGraph &) = delete;
 };
 
-// SetInputMatricesAsCSR, sample/commonutility.h:44-54
-inline void SetInputMatricesAsCSR(CSRGraph &A, const std::string &inputfile) {
+// SetInputMatricesAsCSR, sample/commonutility.h:44-54.  `use_cache`: keep / reuse "<input>.f2vcsr", the binary
+// CSR of the parsed file (the same arrays, so training is bit-identical); an input that already ends in
+// ".f2vcsr" is read as such.
+inline void SetInputMatricesAsCSR(CSRGraph &A, const std::string &inputfile, bool use_cache = false) {
+    const std::string ext = ".f2vcsr";
+    const bool is_bin = inputfile.size() > ext.size() && inputfile.compare(inputfile.size() - ext.size(), ext.size(), ext) == 0;
+    const std::string cache = is_bin ? inputfile : inputfile + ext;
+    if (is_bin || use_cache) {
+        if (f2v_read_csr_bin(cache.c_str(), &A.rows, &A.nnz, &A.rowptr, &A.colids) == F2V_OK) {
+            std::cout << "Reading binary CSR cache:" << cache << std::endl;
+            std::cout << "Input Matrix: Rows = " << A.rows << ", nnz = " << A.nnz << std::endl;
+            return;
+        }
+        if (is_bin) throw std::runtime_error(f2v_last_error());
+    }
     std::cout << "Reading input matrices in text (ascii)... " << std::endl;
     std::cout << "Input File Directory:" << inputfile << std::endl;
     if (f2v_read_mtx(inputfile.c_str(), &A.rows, &A.nnz, &A.rowptr, &A.colids) != F2V_OK) throw std::runtime_error(f2v_last_error());
     std::cout << "Input Matrix: Rows = " << A.rows << ", nnz = " << A.nnz << std::endl;
+    if (use_cache && f2v_write_csr_bin(cache.c_str(), A.rowptr, A.colids, A.rows, A.nnz) != F2V_OK)
+        std::cerr << "warning: " << f2v_last_error() << std::endl;
 }
 
 class algorithms {
@@ -44,6 +59,7 @@ class algorithms {
     INDEXTYPE DIM, rows;
     std::string filename, outputdir;
     double gpu_train_seconds = 0.0;  // device time of the epoch loop alone
+    bool binary_output = false;      // also write "<name>.bin": raw fp32 N x D (readBinEmbeddings format)
     f2v_stats stats{};
 
     algorithms(CSRGraph &A_csr, std::string input, std::string outputd, INDEXTYPE dim, VALUETYPE /*gamma*/, INDEXTYPE /*bsize*/, int device = 0)
@@ -75,6 +91,7 @@ class algorithms {
         std::vector<float> x((size_t)rows * DIM);
         check(f2v_get_embeddings(h, x.data()));
         check(f2v_write_embd(name, x.data(), rows, DIM));
+        if (binary_output) check(f2v_write_embd_bin((std::string(name) + ".bin").c_str(), x.data(), rows, DIM));
     }
 
    private:

@@ -1,7 +1,8 @@
 // cli_main.cpp -- ./bin/Force2Vec: the reference's process boundary (Test/Force2Vec.cpp) over
 // libf2v.  Same flags, defaults, messages, exit codes, output file names and Results.txt line;
 // `-threads` and `-gamma` are accepted and unused (the force kernels run on the MI355X).
-// Additional flags: -device <int>, -seed <int> (default 1, the reference's srand(1)).
+// Additional flags: -device <int>, -seed <int> (default 1, the reference's srand(1)), -cache 1 (keep/reuse a
+// binary CSR "<input>.f2vcsr"), -binout 1 (also write "<output>.embd.bin", raw fp32 N x D).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -34,6 +35,8 @@ static void helpmessage() {
     printf("-bs <int>, 1 = draw nsamples*batch negative samples per minibatch (options 5 and 6).\n");
     printf("-device <int>, HIP device ordinal. (default:0)\n");
     printf("-seed <int>, srand() seed. (default:1)\n");
+    printf("-cache <int>, 1 = keep / reuse the binary CSR <input>.f2vcsr (an input ending in .f2vcsr is read directly).\n");
+    printf("-binout <int>, 1 = also write <output file>.bin, raw fp32 N x D (the scorers' binary embedding format).\n");
     printf("-h, show help message.\n");
 }
 
@@ -42,7 +45,7 @@ static int TestAlgorithms(int argc, char *argv[]) {
     INDEXTYPE batchsize = 384, iterations = 1200, numberOfThreads = std::thread::hardware_concurrency(), dim = 128, option = 5, nsamples = 5;
     string inputfile = "", outputfile = "", algoname = "Force2Vec:t-distribution with negative sampling", initname = "RAND";
     INDEXTYPE bs = 0;
-    int device = 0;
+    int device = 0, cache = 0, binout = 0;
     unsigned seed = 1;
     for (int p = 0; p < argc; p++) {
         const bool has_val = p + 1 < argc;
@@ -61,6 +64,8 @@ static int TestAlgorithms(int argc, char *argv[]) {
         else if (strcmp(argv[p], "-bs") == 0) bs = atoi(argv[p + 1]);
         else if (strcmp(argv[p], "-device") == 0) device = atoi(argv[p + 1]);
         else if (strcmp(argv[p], "-seed") == 0) seed = (unsigned)atoi(argv[p + 1]);
+        else if (strcmp(argv[p], "-cache") == 0) cache = atoi(argv[p + 1]);
+        else if (strcmp(argv[p], "-binout") == 0) binout = atoi(argv[p + 1]);
         else if (strcmp(argv[p], "-lr") == 0) lr = atof(argv[p + 1]);
         else if (strcmp(argv[p], "-nsamples") == 0) nsamples = atoi(argv[p + 1]);
         else if (strcmp(argv[p], "-option") == 0) {
@@ -89,8 +94,9 @@ static int TestAlgorithms(int argc, char *argv[]) {
     vector<VALUETYPE> outputvec;
     try {
         CSRGraph A_csr;
-        SetInputMatricesAsCSR(A_csr, inputfile);
+        SetInputMatricesAsCSR(A_csr, inputfile, cache != 0);
         algorithms algo(A_csr, inputfile, outputfile, dim, gamma, batchsize, device);
+        algo.binary_output = binout != 0;
         algo.srand(seed);
         cout << "Running: " << algoname << endl;
         if (option == 5) outputvec = bs == 0 ? algo.AlgoForce2VecNS(iterations, numberOfThreads, batchsize, nsamples, lr)

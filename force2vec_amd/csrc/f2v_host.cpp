@@ -194,6 +194,54 @@ int f2v_write_embd(const char *path, const float *x, uint32_t n, uint32_t dim) {
     return F2V_OK;
 }
 
+static const char kCsrMagic[8] = {'F', '2', 'V', 'C', 'S', 'R', '1', 0};
+
+int f2v_write_csr_bin(const char *path, const uint32_t *rowptr, const uint32_t *colids, uint32_t n, uint64_t nnz) {
+    if (!path || !rowptr || (!colids && nnz)) return fail(F2V_EINVAL, "f2v_write_csr_bin: null argument");
+    FILE *fp = fopen(path, "wb");
+    if (!fp) return fail(F2V_EIO, "f2v_write_csr_bin: cannot open %s: %s", path, strerror(errno));
+    const uint32_t hdr[2] = {n, 0};
+    bool ok = fwrite(kCsrMagic, 1, 8, fp) == 8 && fwrite(hdr, 4, 2, fp) == 2 && fwrite(&nnz, 8, 1, fp) == 1 &&
+              fwrite(rowptr, 4, (size_t)n + 1, fp) == (size_t)n + 1 && (nnz == 0 || fwrite(colids, 4, nnz, fp) == nnz);
+    ok = (fclose(fp) == 0) && ok;
+    return ok ? F2V_OK : fail(F2V_EIO, "f2v_write_csr_bin: short write to %s", path);
+}
+
+int f2v_read_csr_bin(const char *path, uint32_t *n_out, uint64_t *nnz_out, uint32_t **rowptr_out, uint32_t **colids_out) {
+    if (!path || !n_out || !nnz_out || !rowptr_out || !colids_out) return fail(F2V_EINVAL, "f2v_read_csr_bin: null argument");
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return fail(F2V_EIO, "f2v_read_csr_bin: cannot open %s: %s", path, strerror(errno));
+    char magic[8];
+    uint32_t hdr[2];
+    uint64_t nnz = 0;
+    if (fread(magic, 1, 8, fp) != 8 || memcmp(magic, kCsrMagic, 8) != 0 || fread(hdr, 4, 2, fp) != 2 || fread(&nnz, 8, 1, fp) != 1) {
+        fclose(fp);
+        return fail(F2V_EIO, "f2v_read_csr_bin: %s is not an F2VCSR1 file", path);
+    }
+    const uint32_t n = hdr[0];
+    if (nnz >= 0xFFFFFFFFull) { fclose(fp); return fail(F2V_EINVAL, "f2v_read_csr_bin: nnz exceeds 32-bit row pointers"); }
+    uint32_t *rowptr = (uint32_t *)malloc(((size_t)n + 1) * 4), *colids = (uint32_t *)malloc((nnz ? nnz : 1) * 4);
+    if (!rowptr || !colids) { free(rowptr); free(colids); fclose(fp); return fail(F2V_ENOMEM, "f2v_read_csr_bin: out of memory"); }
+    bool ok = fread(rowptr, 4, (size_t)n + 1, fp) == (size_t)n + 1 && (nnz == 0 || fread(colids, 4, nnz, fp) == nnz);
+    fclose(fp);
+    ok = ok && rowptr[0] == 0 && rowptr[n] == nnz;
+    for (uint32_t i = 0; ok && i < n; i++) ok = rowptr[i] <= rowptr[i + 1];
+    for (uint64_t k = 0; ok && k < nnz; k++) ok = colids[k] < n;
+    if (!ok) { free(rowptr); free(colids); return fail(F2V_EIO, "f2v_read_csr_bin: %s is truncated or inconsistent", path); }
+    *n_out = n; *nnz_out = nnz; *rowptr_out = rowptr; *colids_out = colids;
+    return F2V_OK;
+}
+
+int f2v_write_embd_bin(const char *path, const float *x, uint32_t n, uint32_t dim) {
+    if (!path || !x) return fail(F2V_EINVAL, "f2v_write_embd_bin: null argument");
+    FILE *fp = fopen(path, "wb");
+    if (!fp) return fail(F2V_EIO, "f2v_write_embd_bin: cannot open %s: %s", path, strerror(errno));
+    const size_t total = (size_t)n * dim;
+    bool ok = fwrite(x, sizeof(float), total, fp) == total;
+    ok = (fclose(fp) == 0) && ok;
+    return ok ? F2V_OK : fail(F2V_EIO, "f2v_write_embd_bin: short write to %s", path);
+}
+
 int f2v_output_name(const char *input, const char *outdir, int option, int bs_mode, uint32_t batch, uint32_t dim,
                     uint32_t iters, uint32_t ns, char *out, size_t out_len) {
     if (!input || !outdir || !out) return fail(F2V_EINVAL, "f2v_output_name: null argument");

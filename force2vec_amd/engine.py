@@ -146,6 +146,12 @@ def write_embd(path, X):
     check(_lib.lib().f2v_write_embd(str(path).encode(), _f32(X), X.shape[0], X.shape[1]))
 
 
+def write_embd_bin(path, X):
+    """Raw fp32 N x D file (the scorers' readBinEmbeddings format, runnodeclassclust.py:81-100)."""
+    X = np.ascontiguousarray(X, dtype=np.float32)
+    check(_lib.lib().f2v_write_embd_bin(str(path).encode(), _f32(X), X.shape[0], X.shape[1]))
+
+
 def output_name(input_path, outdir, option, bs_mode, batch, dim, iters, ns):
     buf = C.create_string_buffer(4096)
     check(_lib.lib().f2v_output_name(str(input_path).encode(), str(outdir).encode(), option, bs_mode, batch, dim, iters, ns, buf, len(buf)))

@@ -8,14 +8,13 @@ import numpy as np
 from . import _lib
 
 
-def read_mtx(path):
-    """-> (rowptr u32[n+1], colids u32[nnz]) as SetInputMatricesAsCSR builds them (sample/commonutility.h:44-54)."""
+def _read_with(fn, path):
     L = _lib.lib()
     n = C.c_uint32()
     nnz = C.c_uint64()
     rp = _lib.u32p()
     ci = _lib.u32p()
-    _lib.check(L.f2v_read_mtx(str(path).encode(), C.byref(n), C.byref(nnz), C.byref(rp), C.byref(ci)))
+    _lib.check(getattr(L, fn)(str(path).encode(), C.byref(n), C.byref(nnz), C.byref(rp), C.byref(ci)))
     try:
         rowptr = np.ctypeslib.as_array(rp, shape=(n.value + 1,)).copy()
         colids = np.ctypeslib.as_array(ci, shape=(max(nnz.value, 1),)).copy()[: nnz.value]
@@ -23,6 +22,23 @@ def read_mtx(path):
         L.f2v_free(rp)
         L.f2v_free(ci)
     return rowptr, colids
+
+
+def read_mtx(path):
+    """-> (rowptr u32[n+1], colids u32[nnz]) as SetInputMatricesAsCSR builds them (sample/commonutility.h:44-54)."""
+    return _read_with("f2v_read_mtx", path)
+
+
+def read_csr_bin(path):
+    """Binary CSR cache written by write_csr_bin / `Force2Vec -cache 1` (format in include/f2v.h)."""
+    return _read_with("f2v_read_csr_bin", path)
+
+
+def write_csr_bin(path, rowptr, colids):
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.uint32)
+    colids = np.ascontiguousarray(colids, dtype=np.uint32)
+    _lib.check(_lib.lib().f2v_write_csr_bin(str(path).encode(), rowptr.ctypes.data_as(_lib.u32p), colids.ctypes.data_as(_lib.u32p),
+                                           len(rowptr) - 1, len(colids)))
 
 
 def csr_from_undirected_edges(n, src, dst):

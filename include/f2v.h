@@ -138,6 +138,16 @@ int f2v_write_embd(const char *path, const float *x, uint32_t n, uint32_t dim);
 int f2v_output_name(const char *input, const char *outdir, int option, int bs_mode, uint32_t batch, uint32_t dim,
                     uint32_t iters, uint32_t ns, char *out, size_t out_len);
 
+/* SURVEY 8f "next" rows on the data-format side of the path.
+ * Binary CSR cache (text parsing of 10^8-edge files dominates wall time otherwise): little-endian
+ * "F2VCSR1\0", u32 n, u32 reserved, u64 nnz, u32 rowptr[n+1], u32 colids[nnz] -- exactly the arrays
+ * f2v_read_mtx returns, so a cached graph trains bit-identically. */
+int f2v_write_csr_bin(const char *path, const uint32_t *rowptr, const uint32_t *colids, uint32_t n, uint64_t nnz);
+int f2v_read_csr_bin(const char *path, uint32_t *n_out, uint64_t *nnz_out, uint32_t **rowptr_out, uint32_t **colids_out);
+/* Raw fp32 N x D embedding file, the format the reference's scorers read with readBinEmbeddings
+ * (performancescores/runnodeclassclust.py:81-100); text .embd of 16 M x 128 values is ~19 GB. */
+int f2v_write_embd_bin(const char *path, const float *x, uint32_t n, uint32_t dim);
+
 /* Stand-alone libc rand() stream (glibc TYPE_3), for hosts that pre-draw sample ids. */
 typedef struct f2v_rng f2v_rng;
 f2v_rng *f2v_rng_create(uint32_t seed);

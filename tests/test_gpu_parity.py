@@ -248,6 +248,24 @@ def test_cli_drop_in(F, tmp_path):
     assert np.abs(got - O.read_embd(str(tmp_path / "ref.embd"))).max() < 3e-5
 
 
+def test_cli_binary_cache_and_output(F, tmp_path):
+    exe = os.path.join(ROOT, "bin", "Force2Vec")
+    out = str(tmp_path) + "/"
+    mtx = str(tmp_path / "karate.mtx")
+    open(mtx, "wb").write(open(golden_graph_path("karate.mtx"), "rb").read())
+    args = ["-output", out, "-iter", "5", "-batch", "16", "-dim", "64", "-option", "6", "-binout", "1"]
+    r1 = subprocess.run([exe, "-input", mtx, "-cache", "1"] + args, cwd=out, capture_output=True, text=True)
+    assert r1.returncode == 0 and os.path.exists(mtx + ".f2vcsr"), r1.stdout + r1.stderr
+    first = open(out + "karate.mtxF2VWNS16D64IT5NS5.embd", "rb").read()
+    r2 = subprocess.run([exe, "-input", mtx, "-cache", "1"] + args, cwd=out, capture_output=True, text=True)
+    assert r2.returncode == 0 and "Reading binary CSR cache" in r2.stdout
+    assert open(out + "karate.mtxF2VWNS16D64IT5NS5.embd", "rb").read() == first
+    X = np.fromfile(out + "karate.mtxF2VWNS16D64IT5NS5.embd.bin", np.float32).reshape(-1, 64)
+    rowptr, colids = O.read_mtx(mtx)
+    want = O.train(6, rowptr, colids, 64, 5, 16, order=O.ORDER_TREE, chunk=8)
+    assert np.array_equal(X, want)
+
+
 def test_full_size_sampled_rows(F):
     """RMAT scale-16 (65 536 vertices, ~1 M nnz, hubs of thousands of neighbours) at D = 128: one
     epoch in 4 minibatches, checked on sampled rows (hubs included) against the oracle's row

@@ -138,3 +138,20 @@ def test_cli_argument_behaviour(tmp_path):
     assert r.returncode == 1 and "out of scope" in r.stdout
     r = subprocess.run([exe, "-input", str(tmp_path / "nope.mtx")], capture_output=True, text=True, cwd=str(tmp_path))
     assert r.returncode == 2 and "cannot open" in r.stderr
+
+
+def test_binary_csr_cache_and_binary_embd(tmp_path):
+    rp, ci = F.read_mtx(golden_graph_path("cora.mtx"))
+    p = tmp_path / "cora.f2vcsr"
+    F.write_csr_bin(p, rp, ci)
+    rp2, ci2 = F.read_csr_bin(p)
+    assert np.array_equal(rp, rp2) and np.array_equal(ci, ci2)
+    open(p, "r+b").truncate(os.path.getsize(p) - 8)
+    with pytest.raises(_lib.F2VError):
+        F.read_csr_bin(p)
+    with pytest.raises(_lib.F2VError):
+        F.read_csr_bin(golden_graph_path("cora.mtx"))
+    X = np.random.default_rng(0).standard_normal((37, 16)).astype(np.float32)
+    F.write_embd_bin(tmp_path / "x.bin", X)
+    D = np.fromfile(tmp_path / "x.bin", np.float32)  # readBinEmbeddings, runnodeclassclust.py:81-86
+    assert np.array_equal(D.reshape(-1, 16), X)
