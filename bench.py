@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--option", type=int, default=5)
     ap.add_argument("--hub-chunk", type=int, default=-1)
+    ap.add_argument("--param", action="append", default=[], help="engine tunable name=value (repeatable)")
     ap.add_argument("--cpu-scale", type=int, default=17)
     ap.add_argument("--cpu-iters", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -160,6 +161,9 @@ def main():
     eng = F.Engine(rowptr, colids, args.dim, device=local_rank)
     if args.hub_chunk >= 0:
         eng.set_param("hub_chunk", args.hub_chunk)
+    for kv in args.param:
+        k, v = kv.split("=")
+        eng.set_param(k, int(v))
     eng.srand(1)
     eng.init_embeddings(F._lib.INIT_SYMMETRIC if args.option in (5, 8, 11) else F._lib.INIT_UNIT)
 

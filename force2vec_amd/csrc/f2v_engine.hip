@@ -1,9 +1,9 @@
 // f2v_engine.hip -- HBM-resident Force2Vec engine behind the C ABI of include/f2v.h.
 //
 // Device layout (all in the HBM of one MI355X):
-//   X          fp32 [N x D] row-major (rows 4*D bytes apart: 512 B at D = 128)
+//   X[2]       fp32 [(N+pad) x D] row-major (rows 4*D bytes apart: 512 B at D = 128): the current matrix and
+//              the one this epoch's new rows are written to; they swap when an epoch completes
 //   rowptr     u32  [N+1], colids u32 [nnz]           (the reference's CSR, sample/CSR.h:89-96)
-//   stage[2]   fp32 [batch rows x D]  new rows of the pending / current minibatch (ping-pong)
 //   partials   fp32 [hub chunks x D]  partial force sums of split hub rows
 //   sample ids u32, walks u32 [5N], sigmoid table fp32 [2048]
 // The host side only sequences launches; every arithmetic step runs in f2v_kernels.hip.h.
@@ -34,6 +34,7 @@ using namespace f2v;
                         hipGetErrorString(e__), __FILE__, __LINE__);                                   \
     } while (0)
 
+constexpr uint32_t kPadRows = 4096;  // slack behind row N for the padded in-place all-gather of the last minibatch
 constexpr int kMaxFinLevels = 32;  // fan-in >= 2: 2^32 chunks
 struct Plan {
     size_t item_off = 0;
@@ -54,8 +55,8 @@ struct f2v_ctx {
     std::vector<uint32_t> rowptr, colids;  // host copies: hub planning, walk generation, statistics
     uint32_t *d_rowptr = nullptr, *d_colids = nullptr, *d_walks = nullptr, *d_ids = nullptr;
     size_t ids_cap = 0;
-    float *d_X = nullptr, *d_stage[2] = {nullptr, nullptr}, *d_partials = nullptr, *d_table = nullptr;
-    uint32_t stage_cap = 0;
+    float *d_X[2] = {nullptr, nullptr}, *d_partials = nullptr, *d_table = nullptr;
+    int cur = 0;  // d_X[cur]: current matrix; d_X[cur^1]: receives the rows updated this epoch
     bool have_x = false, have_walks = false;
     Rand rng;
     // work-item plans (one per distinct launch: row range x neighbour source), see plan_for()
@@ -69,11 +70,12 @@ struct f2v_ctx {
     FinItem *d_hubs = nullptr;
     size_t d_items_cap = 0, d_hubs_cap = 0, d_items_valid = 0, d_hubs_valid = 0;
     size_t partial_slots = 0, max_slots = 0;
-    // pending (staged, not yet committed) minibatch
-    bool pending = false;
-    uint32_t p_lo = 0, p_hi = 0;
-    int p_idx = 0;
+    // rows [upd_lo, upd_hi) have been updated since the last swap/fold and live in d_X[cur^1]
+    uint32_t upd_lo = 0, upd_hi = 0;
+    bool pending = false;             // a minibatch has been stepped since the last flush
+    uint32_t p_lo = 0, p_hi = 0;      // ... and this is it (multi-GPU exchange window)
     int waves_per_block = 4;
+    int rows_in_flight = 4;
     f2v_stats stats{};
 };
 
@@ -208,19 +210,6 @@ int upload_plans(f2v_ctx *c) {
     return F2V_OK;
 }
 
-int reserve_stage(f2v_ctx *c, uint32_t rows) {
-    if (rows <= c->stage_cap) return F2V_OK;
-    if (c->pending) return fail(F2V_ESTATE, "staging buffer cannot grow while a minibatch is pending (flush first)");
-    HIPC(hipStreamSynchronize(c->stream));  // a commit of the old buffers may still be in flight
-    for (int k = 0; k < 2; k++) {
-        if (c->d_stage[k]) (void)hipFree(c->d_stage[k]);
-        c->d_stage[k] = nullptr;
-        HIPC(hipMalloc((void **)&c->d_stage[k], (size_t)rows * c->D * sizeof(float)));
-    }
-    c->stage_cap = rows;
-    return F2V_OK;
-}
-
 int reserve_ids(f2v_ctx *c, size_t count) {
     if (count <= c->ids_cap) return F2V_OK;
     HIPC(hipStreamSynchronize(c->stream));
@@ -232,10 +221,10 @@ int reserve_ids(f2v_ctx *c, size_t count) {
 }
 
 template <int VEC, bool EXACT>
-void launch_commit_t(f2v_ctx *c, const float *stage, uint32_t lo, uint32_t rows) {
+void launch_commit_t(f2v_ctx *c, uint32_t lo, uint32_t rows) {
     const int wpb = 4;
     const uint32_t blocks = std::min<uint32_t>((rows + wpb - 1) / wpb, 4096u);
-    hipLaunchKernelGGL((commit_kernel<VEC, EXACT>), dim3(blocks), dim3(64 * wpb), 0, c->stream, c->d_X, stage, lo, rows, c->D);
+    hipLaunchKernelGGL((commit_kernel<VEC, EXACT>), dim3(blocks), dim3(64 * wpb), 0, c->stream, c->d_X[c->cur], c->d_X[c->cur ^ 1], lo, rows, c->D);
 }
 
 template <typename F>
@@ -259,14 +248,20 @@ int dispatch_layout(f2v_ctx *c, F &&f) {
     return fail(F2V_EINVAL, "unsupported dimension %u", c->D);
 }
 
+// Make d_X[cur] the whole, up-to-date matrix: a completed epoch (all N rows updated) just swaps the two
+// matrices; a partial range is folded back with a copy.
 int flush_pending(f2v_ctx *c) {
-    if (!c->pending) return F2V_OK;
-    const float *stage = c->d_stage[c->p_idx];
-    const uint32_t lo = c->p_lo, rows = c->p_hi - c->p_lo;
-    int rc = dispatch_layout(c, [&](auto V, auto E) { launch_commit_t<decltype(V)::value, decltype(E)::value>(c, stage, lo, rows); });
-    if (rc != F2V_OK) return rc;
-    HIPC(hipGetLastError());
     c->pending = false;
+    if (c->upd_hi == c->upd_lo) return F2V_OK;
+    if (c->upd_lo == 0 && c->upd_hi == c->n) {
+        c->cur ^= 1;
+    } else {
+        const uint32_t lo = c->upd_lo, rows = c->upd_hi - c->upd_lo;
+        int rc = dispatch_layout(c, [&](auto V, auto E) { launch_commit_t<decltype(V)::value, decltype(E)::value>(c, lo, rows); });
+        if (rc != F2V_OK) return rc;
+        HIPC(hipGetLastError());
+    }
+    c->upd_lo = c->upd_hi = 0;
     return F2V_OK;
 }
 
@@ -283,26 +278,18 @@ int math_of_option(int option) {
 int launch_step(f2v_ctx *c, int math, uint32_t batch_lo, uint32_t batch_hi, uint32_t row_lo, uint32_t row_hi,
                 const uint32_t *d_ids, uint32_t ns, float lr, int bs_mode) {
     int rc;
-    if (c->pending && !(c->p_hi <= batch_lo || batch_hi <= c->p_lo)) {
-        // the pending batch overlaps this one (single-batch epochs): commit it with its own launch
+    if (c->upd_hi != c->upd_lo && batch_lo != c->upd_hi) {
+        // not the continuation of the updated range (a new epoch, or batches out of order): swap / fold first
         if ((rc = flush_pending(c)) != F2V_OK) return rc;
-    }
-    const uint32_t brows = batch_hi - batch_lo;
-    if (brows > c->stage_cap) {
-        if ((rc = flush_pending(c)) != F2V_OK) return rc;
-        if ((rc = reserve_stage(c, brows)) != F2V_OK) return rc;
     }
     const bool walk = (math == 7);
     const Plan plan = plan_for(c, row_lo, row_hi, walk);  // by value: upload_plans may not move it, but keep it simple
     if ((rc = upload_plans(c)) != F2V_OK) return rc;
-    const int cur = c->pending ? (c->p_idx ^ 1) : 0;
-
     StepArgs a{};
-    a.X = c->d_X;
+    a.X = c->d_X[c->cur];
+    a.Xn = c->d_X[c->cur ^ 1];
     a.rowptr = c->d_rowptr;
     a.nbr_ids = walk ? c->d_walks : c->d_colids;
-    a.stage_prev = c->pending ? c->d_stage[c->p_idx] : nullptr;
-    a.stage_cur = c->d_stage[cur];
     a.partials = c->d_partials;
     a.sample_ids = d_ids;
     a.items = c->d_items + plan.item_off;
@@ -310,8 +297,8 @@ int launch_step(f2v_ctx *c, int math, uint32_t batch_lo, uint32_t batch_hi, uint
     a.D = c->D;
     a.batch_lo = batch_lo;
     a.n_items = plan.n_items;
-    a.prev_lo = c->pending ? c->p_lo : 0;
-    a.prev_rows = c->pending ? (c->p_hi - c->p_lo) : 0;
+    a.upd_lo = c->upd_lo;
+    a.upd_rows = c->upd_hi - c->upd_lo;
     a.ns = ns;
     a.bs_mode = bs_mode ? 1u : 0u;
     a.lr = lr;
@@ -320,14 +307,17 @@ int launch_step(f2v_ctx *c, int math, uint32_t batch_lo, uint32_t batch_hi, uint
     const bool quarter = c->use_quarter && c->exact && (c->D == 64 || c->D == 128 || c->D == 256);
     const uint32_t per_wave = quarter ? 4u : 1u;
     const uint32_t waves = (plan.n_items + per_wave - 1) / per_wave;
-    // enough blocks for the items; when a rank has few or no rows of this batch, still enough to commit the pending one
-    const uint32_t commit_waves = std::min<uint32_t>((a.prev_rows + per_wave - 1) / per_wave, 8192u);
-    const uint32_t blocks = std::max<uint32_t>(1u, (std::max(waves, commit_waves) + wpb - 1) / wpb);
-    if (quarter) {
+    const uint32_t blocks = (waves + wpb - 1) / wpb;  // 0 when this rank has no row of the batch
+    if (blocks == 0) {
+        // nothing to compute here; the range bookkeeping below still advances
+    } else if (quarter) {
         const int nb = (int)(c->D / 64);
-#define F2V_Q(OPT, NB) hipLaunchKernelGGL((qstep_kernel<OPT, NB>), dim3(blocks), dim3(64 * wpb), 0, c->stream, a)
-        if (math == 5) { if (nb == 1) F2V_Q(5, 1); else if (nb == 2) F2V_Q(5, 2); else F2V_Q(5, 4); }
-        else { if (nb == 1) F2V_Q(6, 1); else if (nb == 2) F2V_Q(6, 2); else F2V_Q(6, 4); }
+#define F2V_Q(OPT, NB, U) hipLaunchKernelGGL((qstep_kernel<OPT, NB, U>), dim3(blocks), dim3(64 * wpb), 0, c->stream, a)
+        // rows in flight per quarter: 4 (D = 128: 80 VGPRs, 6 waves/SIMD); 8 is selectable at D = 128 and
+        // measured 3-9 % slower on RMAT-20 (116 VGPRs, 4 waves/SIMD); D = 64 has the registers for 8
+        const bool u8 = (c->rows_in_flight == 8);
+        if (math == 5) { if (nb == 1) F2V_Q(5, 1, 8); else if (nb == 2) { if (u8) F2V_Q(5, 2, 8); else F2V_Q(5, 2, 4); } else F2V_Q(5, 4, 4); }
+        else { if (nb == 1) F2V_Q(6, 1, 8); else if (nb == 2) { if (u8) F2V_Q(6, 2, 8); else F2V_Q(6, 2, 4); } else F2V_Q(6, 4, 4); }
 #undef F2V_Q
     } else {
         rc = dispatch_layout(c, [&](auto V, auto E) {
@@ -343,9 +333,9 @@ int launch_step(f2v_ctx *c, int math, uint32_t batch_lo, uint32_t batch_hi, uint
     HIPC(hipGetLastError());
     for (int lev = 0; lev < plan.n_levels; lev++) {
         FinalizeArgs f{};
-        f.X = c->d_X;
+        f.X = a.X;
         f.partials = c->d_partials;
-        f.stage_cur = a.stage_cur;
+        f.Xn = a.Xn;
         f.items = c->d_hubs + plan.fin_off[lev];
         f.n_items = plan.fin_cnt[lev];
         f.D = c->D;
@@ -364,10 +354,11 @@ int launch_step(f2v_ctx *c, int math, uint32_t batch_lo, uint32_t batch_hi, uint
     }
     c->stats.hub_rows += plan.n_hubs;
     c->stats.hub_chunks += plan.n_chunks;
+    if (c->upd_hi == c->upd_lo) c->upd_lo = batch_lo;
+    c->upd_hi = batch_hi;
     c->pending = true;
     c->p_lo = batch_lo;
     c->p_hi = batch_hi;
-    c->p_idx = cur;
 
     // statistics: algorithmic bytes of SURVEY 8d -- nnz*(4D+4) + rows*(8D+4) + ns*(4D+4) per minibatch
     const uint64_t rows = row_hi - row_lo;
@@ -439,7 +430,7 @@ int f2v_create(const uint32_t *rowptr, const uint32_t *colids, uint32_t n, uint6
     HIPB(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPB(hipMalloc((void **)&c->d_rowptr, ((size_t)n + 1) * sizeof(uint32_t)));
     HIPB(hipMalloc((void **)&c->d_colids, std::max<size_t>(nnz, 1) * sizeof(uint32_t)));
-    HIPB(hipMalloc((void **)&c->d_X, (size_t)n * dim * sizeof(float)));
+    for (int k = 0; k < 2; k++) HIPB(hipMalloc((void **)&c->d_X[k], ((size_t)n + kPadRows) * dim * sizeof(float)));
     HIPB(hipMalloc((void **)&c->d_table, kSmTableSize * sizeof(float)));
     HIPB(hipMemcpy(c->d_rowptr, rowptr, ((size_t)n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
     if (nnz) HIPB(hipMemcpy(c->d_colids, colids, nnz * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -455,7 +446,7 @@ int f2v_destroy(f2v_handle c) {
     if (!c) return F2V_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *ptrs[] = {c->d_rowptr, c->d_colids, c->d_walks, c->d_ids, c->d_X, c->d_stage[0], c->d_stage[1],
+    void *ptrs[] = {c->d_rowptr, c->d_colids, c->d_walks, c->d_ids, c->d_X[0], c->d_X[1],
                     c->d_partials, c->d_table, c->d_items, c->d_hubs};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -494,7 +485,8 @@ int f2v_init_embeddings(f2v_handle c, int kind) {
     init_embeddings_host(c->rng, x.data(), total, kind);
     HIPC(hipStreamSynchronize(c->stream));
     c->pending = false;
-    HIPC(hipMemcpy(c->d_X, x.data(), total * sizeof(float), hipMemcpyHostToDevice));
+    c->upd_lo = c->upd_hi = 0;
+    HIPC(hipMemcpy(c->d_X[c->cur], x.data(), total * sizeof(float), hipMemcpyHostToDevice));
     c->have_x = true;
     return F2V_OK;
 }
@@ -504,7 +496,8 @@ int f2v_set_embeddings(f2v_handle c, const float *x) {
     HIPC(hipSetDevice(c->device));
     HIPC(hipStreamSynchronize(c->stream));
     c->pending = false;
-    HIPC(hipMemcpy(c->d_X, x, (size_t)c->n * c->D * sizeof(float), hipMemcpyHostToDevice));
+    c->upd_lo = c->upd_hi = 0;
+    HIPC(hipMemcpy(c->d_X[c->cur], x, (size_t)c->n * c->D * sizeof(float), hipMemcpyHostToDevice));
     c->have_x = true;
     return F2V_OK;
 }
@@ -516,7 +509,7 @@ int f2v_get_embeddings(f2v_handle c, float *x_out) {
     int rc = flush_pending(c);
     if (rc != F2V_OK) return rc;
     HIPC(hipStreamSynchronize(c->stream));
-    HIPC(hipMemcpy(x_out, c->d_X, (size_t)c->n * c->D * sizeof(float), hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(x_out, c->d_X[c->cur], (size_t)c->n * c->D * sizeof(float), hipMemcpyDeviceToHost));
     return F2V_OK;
 }
 
@@ -557,6 +550,11 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
     }
     if (!strcmp(name, "quarter_wave")) {
         c->use_quarter = value != 0;
+        return F2V_OK;
+    }
+    if (!strcmp(name, "rows_in_flight")) {
+        if (value != 4 && value != 8) return fail(F2V_EINVAL, "rows_in_flight must be 4 or 8");
+        c->rows_in_flight = (int)value;
         return F2V_OK;
     }
     if (!strcmp(name, "waves_per_block")) {
@@ -646,20 +644,16 @@ int f2v_synchronize(f2v_handle c) {
 
 int f2v_stage_reserve(f2v_handle c, uint32_t rows) {
     if (!c) return fail(F2V_EINVAL, "null handle");
-    HIPC(hipSetDevice(c->device));
-    if (rows > c->stage_cap) {
-        int rc = flush_pending(c);
-        if (rc != F2V_OK) return rc;
-        HIPC(hipStreamSynchronize(c->stream));
-    }
-    return reserve_stage(c, rows);
+    // new rows are written in place into the second matrix, which has kPadRows of slack behind row N
+    if (rows > c->n + kPadRows) return fail(F2V_EINVAL, "f2v_stage_reserve: %u rows exceed the matrix", rows);
+    return F2V_OK;
 }
 
 int f2v_stage_device_ptr(f2v_handle c, uint64_t *devptr_out, uint32_t *cap_out) {
     if (!c || !devptr_out) return fail(F2V_EINVAL, "f2v_stage_device_ptr: null argument");
     if (!c->pending) return fail(F2V_ESTATE, "f2v_stage_device_ptr: no minibatch is pending");
-    *devptr_out = (uint64_t)(uintptr_t)c->d_stage[c->p_idx];
-    if (cap_out) *cap_out = c->stage_cap;
+    *devptr_out = (uint64_t)(uintptr_t)(c->d_X[c->cur ^ 1] + (size_t)c->p_lo * c->D);
+    if (cap_out) *cap_out = c->n + kPadRows - c->p_lo;
     return F2V_OK;
 }
 
@@ -668,7 +662,7 @@ int f2v_stage_read(f2v_handle c, uint32_t row_lo, uint32_t row_hi, float *out) {
     if (!c->pending || row_lo < c->p_lo || row_hi > c->p_hi || row_lo > row_hi) return fail(F2V_ESTATE, "f2v_stage_read: rows outside the pending minibatch");
     HIPC(hipSetDevice(c->device));
     HIPC(hipStreamSynchronize(c->stream));
-    HIPC(hipMemcpy(out, c->d_stage[c->p_idx] + (size_t)(row_lo - c->p_lo) * c->D, (size_t)(row_hi - row_lo) * c->D * sizeof(float), hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(out, c->d_X[c->cur ^ 1] + (size_t)row_lo * c->D, (size_t)(row_hi - row_lo) * c->D * sizeof(float), hipMemcpyDeviceToHost));
     return F2V_OK;
 }
 
@@ -677,13 +671,13 @@ int f2v_stage_write(f2v_handle c, uint32_t row_lo, uint32_t row_hi, const float 
     if (!c->pending || row_lo < c->p_lo || row_hi > c->p_hi || row_lo > row_hi) return fail(F2V_ESTATE, "f2v_stage_write: rows outside the pending minibatch");
     HIPC(hipSetDevice(c->device));
     HIPC(hipStreamSynchronize(c->stream));
-    HIPC(hipMemcpy(c->d_stage[c->p_idx] + (size_t)(row_lo - c->p_lo) * c->D, in, (size_t)(row_hi - row_lo) * c->D * sizeof(float), hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(c->d_X[c->cur ^ 1] + (size_t)row_lo * c->D, in, (size_t)(row_hi - row_lo) * c->D * sizeof(float), hipMemcpyHostToDevice));
     return F2V_OK;
 }
 
 int f2v_embeddings_device_ptr(f2v_handle c, uint64_t *out) {
     if (!c || !out) return fail(F2V_EINVAL, "null argument");
-    *out = (uint64_t)(uintptr_t)c->d_X;
+    *out = (uint64_t)(uintptr_t)c->d_X[c->cur];  // the whole matrix only after f2v_flush
     return F2V_OK;
 }
 
@@ -715,11 +709,6 @@ int f2v_train(f2v_handle c, int option, uint32_t iters, uint32_t batch, uint32_t
     const uint64_t ndraw = bs_mode ? (uint64_t)ns * batch : ns;
     const uint64_t stride = bs_mode ? (uint64_t)std::min(batch, n) + ns : ns;  // ids kept per minibatch
     const uint64_t per_epoch = (uint64_t)nb * stride;
-    if ((rc = reserve_stage(c, std::min(batch, n))) != F2V_OK) {
-        if ((rc = flush_pending(c)) != F2V_OK) return rc;
-        HIPC(hipStreamSynchronize(c->stream));
-        if ((rc = reserve_stage(c, std::min(batch, n))) != F2V_OK) return rc;
-    }
     if (c->chunk_auto) {
         const uint32_t ch = auto_chunk(c, batch);
         if (ch != c->chunk) {

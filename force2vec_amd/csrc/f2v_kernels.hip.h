@@ -20,12 +20,16 @@
 //                                 row; every VALU instruction serves four (row, neighbour) pairs.
 //
 // Minibatch sequencing (Jacobi inside a batch, Gauss-Seidel across batches,
-// sample/algorithms.cpp:588-639) without a second launch per batch: the new rows of batch b
-// go to a staging buffer, and the step kernel of batch b+1 (a) commits them to X in its
-// prologue and (b) redirects every read of a batch-b row (neighbour or negative sample) to
-// the staging buffer, so no wave ever reads a row of X that another wave of the same launch
-// writes.  Rows of the CURRENT batch are only read from X (their pre-batch values), which is
-// exactly the reference's snapshot semantics for samples and in-batch neighbours.
+// sample/algorithms.cpp:588-639) with ONE launch per batch and no copy: the embedding matrix
+// exists twice in HBM.  During an epoch the rows already updated (a growing contiguous range
+// [upd_lo, upd_lo+upd_rows)) live in the NEW matrix Xn, all others in the current matrix X; the
+// step kernel of a batch writes its rows to Xn and reads every other row (neighbour or negative
+// sample) from Xn if it lies in the updated range, from X otherwise.  Rows of the CURRENT batch
+// are outside that range, so they are read with their pre-batch values -- exactly the
+// reference's snapshot semantics for samples and in-batch neighbours -- and no wave ever reads
+// a row another wave of the same launch writes.  When the range covers all N rows the two
+// matrices swap roles.  Per row the kernel moves 4D bytes in and 4D bytes out: the algorithmic
+// minimum.
 //
 // Load balance (the GPU counterpart of option 11's nnz-balanced partition,
 // sample/algorithms.cpp:2483-2523): the host cuts every minibatch into work ITEMS -- a whole
@@ -52,19 +56,18 @@ constexpr uint32_t kItemLast = 1u << 29;     // last chunk of its row: also take
 constexpr uint32_t kItemSlotMask = (1u << 28) - 1;
 
 struct StepArgs {
-    float *X;                    // N x D embedding matrix (row-major, fp32)
+    const float *X;              // current N x D embedding matrix (row-major, fp32): rows not yet updated this epoch
+    float *Xn;                   // new matrix: rows of the updated range, and this batch's output
     const uint32_t *rowptr;      // CSR row pointers [N+1]
     const uint32_t *nbr_ids;     // CSR colids, or the epoch's walk samples [5*N] (option 7)
-    const float *stage_prev;     // new rows of the previous (pending) minibatch
-    float *stage_cur;            // new rows of this minibatch
     float *partials;             // hub chunk partial sums of this launch [slots x D]
     const uint32_t *sample_ids;  // negative-sample vertex ids of this minibatch (device)
     const Item *items;           // this launch's work items, longest first
     const float *sm_table;       // 2048-entry sigmoid table
     uint32_t D;
-    uint32_t batch_lo;           // first row of the minibatch (staging row 0)
+    uint32_t batch_lo;           // first row of the minibatch (-bs 1 sample window base)
     uint32_t n_items;
-    uint32_t prev_lo, prev_rows; // pending minibatch to commit / redirect to
+    uint32_t upd_lo, upd_rows;   // rows [upd_lo, upd_lo+upd_rows) are read from Xn
     uint32_t ns;
     uint32_t bs_mode;
     float lr;
@@ -81,7 +84,7 @@ constexpr uint32_t kFinToStage = 0xFFFFFFFFu;
 struct FinalizeArgs {
     const float *X;
     float *partials;
-    float *stage_cur;
+    float *Xn;
     const FinItem *items;
     uint32_t n_items;
     uint32_t D;
@@ -246,8 +249,7 @@ __device__ __forceinline__ void process_list(const StepArgs &a, const uint32_t *
             for (int u = 0; u < U; ++u) {
                 const uint32_t k = (g + u) < cnt ? (g + u) : (cnt - 1);
                 const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)idv, (int)k);
-                const uint32_t pj = j - a.prev_lo;
-                const float *src = (pj < a.prev_rows) ? a.stage_prev + (size_t)pj * D : a.X + (size_t)j * D;
+                const float *src = ((j - a.upd_lo) < a.upd_rows ? a.Xn : a.X) + (size_t)j * D;
                 load_row<VEC, EXACT>(src, lane, D, xj[u]);
             }
 #pragma unroll
@@ -264,24 +266,15 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wpb = blockDim.x >> 6;
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + (threadIdx.x >> 6)));
-    const uint32_t total_waves = gridDim.x * wpb;
     const uint32_t D = a.D;
-
-    // (1) commit the pending minibatch: X[prev rows] = staged rows (K5, algorithms.cpp:629-639)
-    for (uint32_t r = w; r < a.prev_rows; r += total_waves) {
-        float t[VEC];
-        load_row<VEC, EXACT>(a.stage_prev + (size_t)r * D, lane, D, t);
-        store_row<VEC, EXACT>(a.X + (size_t)(a.prev_lo + r) * D, lane, D, t);
-    }
     if (w >= a.n_items) return;
 
-    // (2) this wave's item
     const Item it = a.items[w];
     const uint32_t row = it.row;
     const bool partial = (it.flags & kItemPartial) != 0;
     const bool first_chunk = (it.flags & kItemFirst) != 0;
     const bool last_chunk = (it.flags & kItemLast) != 0;
-    float *out = partial ? a.partials + (size_t)(it.flags & kItemSlotMask) * D : a.stage_cur + (size_t)(row - a.batch_lo) * D;
+    float *out = partial ? a.partials + (size_t)(it.flags & kItemSlotMask) * D : a.Xn + (size_t)row * D;
 
     float xi[VEC], Y[VEC];
     load_row<VEC, EXACT>(a.X + (size_t)row * D, lane, D, xi);
@@ -402,17 +395,15 @@ __device__ __forceinline__ void pair_update_q(const float (&xi)[NB][4], const fl
 
 template <int NB>
 __device__ __forceinline__ const float *row_src(const StepArgs &a, uint32_t j) {
-    const uint32_t pj = j - a.prev_lo;
-    return (pj < a.prev_rows) ? a.stage_prev + (size_t)pj * (64u * NB) : a.X + (size_t)j * (64u * NB);
+    return ((j - a.upd_lo) < a.upd_rows ? a.Xn : a.X) + (size_t)j * (64u * NB);
 }
 
 // One quarter's list of row ids; `cnt` is this quarter's length, `maxcnt` the wave's (uniform).
 // U rows per quarter (4U per wave) are in flight before the first interaction is evaluated; the
 // ids of the next group are fetched one group ahead.
-template <int OPT, int NB, bool NEG>
+template <int OPT, int NB, bool NEG, int U>
 __device__ __forceinline__ void qprocess(const StepArgs &a, const uint32_t *ids, uint32_t cnt, uint32_t maxcnt, uint32_t t,
                                          const float (&xi)[NB][4], float (&Y)[NB][4], double c0) {
-    constexpr int U = 4;
     uint32_t j[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) j[u] = ((uint32_t)u < cnt) ? ids[u] : 0u;
@@ -442,25 +433,16 @@ __device__ __forceinline__ uint32_t wave_max_of_quarters(uint32_t v) {
     return m0 > m1 ? m0 : m1;
 }
 
-template <int OPT, int NB>
+template <int OPT, int NB, int U>
 __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
     constexpr uint32_t D = 64u * NB;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t t = lane & 15u, q = lane >> 4;
     const uint32_t wpb = blockDim.x >> 6;
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + (threadIdx.x >> 6)));
-    const uint32_t total_q = gridDim.x * wpb * 4u;
-
-    // (1) commit the pending minibatch, one row per quarter (K5, algorithms.cpp:629-639)
-    for (uint32_t r = 4u * w + q; r < a.prev_rows; r += total_q) {
-        const float *src = a.stage_prev + (size_t)r * D + t * 4;
-        float *dst = a.X + (size_t)(a.prev_lo + r) * D + t * 4;
-#pragma unroll
-        for (int b = 0; b < NB; ++b) *reinterpret_cast<float4 *>(dst + 64 * b) = *reinterpret_cast<const float4 *>(src + 64 * b);
-    }
     if (4u * w >= a.n_items) return;
 
-    // (2) this quarter's item (quarters past the end of the list idle with cnt = 0)
+    // this quarter's item (quarters past the end of the list idle with cnt = 0)
     const uint32_t idx = 4u * w + q;
     const bool active = idx < a.n_items;
     Item it;
@@ -496,15 +478,15 @@ __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
         c0 = (double)(a.lr * degi);
     }
 
-    qprocess<OPT, NB, false>(a, a.nbr_ids + it.nb, it.cnt, wave_max_of_quarters(it.cnt), t, xi, Y, c0);
+    qprocess<OPT, NB, false, U>(a, a.nbr_ids + it.nb, it.cnt, wave_max_of_quarters(it.cnt), t, xi, Y, c0);
     {
         const uint32_t scnt = (active && last_chunk) ? a.ns : 0u;
         const uint32_t sbase = a.bs_mode ? (row - a.batch_lo) : 0u;
-        qprocess<OPT, NB, true>(a, a.sample_ids + sbase, scnt, wave_max_of_quarters(scnt), t, xi, Y, c0);
+        qprocess<OPT, NB, true, U>(a, a.sample_ids + sbase, scnt, wave_max_of_quarters(scnt), t, xi, Y, c0);
     }
 
     if (active) {
-        float *out = (partial ? a.partials + (size_t)(it.flags & kItemSlotMask) * D : a.stage_cur + (size_t)(row - a.batch_lo) * D) + t * 4;
+        float *out = (partial ? a.partials + (size_t)(it.flags & kItemSlotMask) * D : a.Xn + (size_t)row * D) + t * 4;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             float4 v;
@@ -529,7 +511,7 @@ __global__ __launch_bounds__(256) void hub_finalize_kernel(const FinalizeArgs f)
     const float *p = f.partials + (size_t)h.in_slot * D;
     float Y[VEC];
     load_row<VEC, EXACT>(p, lane, D, Y);
-    constexpr int U = 8;
+    constexpr int U = 16;
     for (uint32_t c = 1; c < h.n; c += U) {
         float P[U][VEC];
 #pragma unroll
@@ -552,21 +534,22 @@ __global__ __launch_bounds__(256) void hub_finalize_kernel(const FinalizeArgs f)
 #pragma unroll
             for (int v = 0; v < VEC; ++v) Y[v] = xi[v] + Y[v];
         }
-        store_row<VEC, EXACT>(f.stage_cur + (size_t)(h.row - f.batch_lo) * D, lane, D, Y);
+        store_row<VEC, EXACT>(f.Xn + (size_t)h.row * D, lane, D, Y);
     } else {
         store_row<VEC, EXACT>(f.partials + (size_t)h.out * D, lane, D, Y);
     }
 }
 
-// X[lo + r] = stage[r] for r < rows (commit without a following step)
+// X[lo + r] = Xn[lo + r] for r < rows: folds a PARTIAL updated range back (out-of-order batches, reading the
+// matrix in the middle of an epoch); a completed epoch swaps the matrices instead.
 template <int VEC, bool EXACT>
-__global__ __launch_bounds__(256) void commit_kernel(float *X, const float *stage, uint32_t lo, uint32_t rows, uint32_t D) {
+__global__ __launch_bounds__(256) void commit_kernel(float *X, const float *Xn, uint32_t lo, uint32_t rows, uint32_t D) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wpb = blockDim.x >> 6;
     const uint32_t total = gridDim.x * wpb;
     for (uint32_t r = blockIdx.x * wpb + (threadIdx.x >> 6); r < rows; r += total) {
         float t[VEC];
-        load_row<VEC, EXACT>(stage + (size_t)r * D, lane, D, t);
+        load_row<VEC, EXACT>(Xn + (size_t)(lo + r) * D, lane, D, t);
         store_row<VEC, EXACT>(X + (size_t)(lo + r) * D, lane, D, t);
     }
 }
