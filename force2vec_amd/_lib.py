@@ -34,6 +34,8 @@ SIGNATURES = {
     "f2v_get_param": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
     "f2v_train": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_int, C.POINTER(C.c_double)]),
     "f2v_minibatch_step": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u32p, C.c_uint32, C.c_uint32, C.c_float, C.c_int]),
+    "f2v_upload_sample_ids": (C.c_int, [C.c_void_p, u32p, C.c_uint64]),
+    "f2v_minibatch_step_at": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_float, C.c_int]),
     "f2v_flush": (C.c_int, [C.c_void_p]),
     "f2v_set_walks": (C.c_int, [C.c_void_p, u32p]),
     "f2v_generate_walks": (C.c_int, [C.c_void_p, u32p]),

@@ -54,7 +54,7 @@ struct f2v_ctx {
     bool exact = false;
     std::vector<uint32_t> rowptr, colids;  // host copies: hub planning, walk generation, statistics
     uint32_t *d_rowptr = nullptr, *d_colids = nullptr, *d_walks = nullptr, *d_ids = nullptr;
-    size_t ids_cap = 0;
+    size_t ids_cap = 0, ids_valid = 0;  // ids_valid: prefix uploaded by f2v_upload_sample_ids
     float *d_X[2] = {nullptr, nullptr}, *d_partials = nullptr, *d_table = nullptr;
     int cur = 0;  // d_X[cur]: current matrix; d_X[cur^1]: receives the rows updated this epoch
     bool have_x = false, have_walks = false;
@@ -619,11 +619,41 @@ int f2v_minibatch_step(f2v_handle c, int option, uint32_t batch_lo, uint32_t bat
     int rc = reserve_ids(c, std::max<size_t>(need, 64));
     if (rc != F2V_OK) return rc;
     // the previous step may still be reading d_ids: order the copy behind it on the stream
+    c->ids_valid = 0;
     if (need) {
         HIPC(hipMemcpyAsync(c->d_ids, sample_ids, need * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         HIPC(hipStreamSynchronize(c->stream));
     }
     return launch_step(c, math, batch_lo, batch_hi, row_lo, row_hi, c->d_ids, ns, lr, bs_mode);
+}
+
+int f2v_upload_sample_ids(f2v_handle c, const uint32_t *ids, uint64_t count) {
+    if (!c || (!ids && count)) return fail(F2V_EINVAL, "f2v_upload_sample_ids: null argument");
+    for (uint64_t k = 0; k < count; k++)
+        if (ids[k] >= c->n) return fail(F2V_EINVAL, "f2v_upload_sample_ids: id %u is not a vertex", ids[k]);
+    HIPC(hipSetDevice(c->device));
+    int rc = reserve_ids(c, std::max<size_t>(count, 64));
+    if (rc != F2V_OK) return rc;
+    HIPC(hipStreamSynchronize(c->stream));  // steps in flight still read the previous ids
+    if (count) HIPC(hipMemcpy(c->d_ids, ids, count * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->ids_valid = count;
+    return F2V_OK;
+}
+
+int f2v_minibatch_step_at(f2v_handle c, int option, uint32_t batch_lo, uint32_t batch_hi, uint32_t row_lo,
+                          uint32_t row_hi, uint64_t ids_offset, uint32_t ns, float lr, int bs_mode) {
+    if (!c) return fail(F2V_EINVAL, "null handle");
+    const int math = math_of_option(option);
+    if (!math) return fail(F2V_EINVAL, "f2v_minibatch_step_at: option %d is outside 5..11", option);
+    if (!c->have_x) return fail(F2V_ESTATE, "f2v_minibatch_step_at: embeddings not initialised");
+    if (batch_lo >= batch_hi || batch_hi > c->n) return fail(F2V_EINVAL, "f2v_minibatch_step_at: bad batch [%u,%u)", batch_lo, batch_hi);
+    if (row_lo < batch_lo || row_hi > batch_hi || row_lo > row_hi) return fail(F2V_EINVAL, "f2v_minibatch_step_at: rows [%u,%u) outside the batch", row_lo, row_hi);
+    if (math == 7 && bs_mode) return fail(F2V_EINVAL, "option 7 has no -bs 1 variant");
+    if (math == 7 && !c->have_walks) return fail(F2V_ESTATE, "option 7 needs f2v_set_walks / f2v_generate_walks first");
+    const uint64_t need = bs_mode ? (uint64_t)(batch_hi - batch_lo) + ns - 1 : ns;
+    if (ids_offset + need > c->ids_valid) return fail(F2V_EINVAL, "f2v_minibatch_step_at: ids [%llu,+%llu) were not uploaded", (unsigned long long)ids_offset, (unsigned long long)need);
+    HIPC(hipSetDevice(c->device));
+    return launch_step(c, math, batch_lo, batch_hi, row_lo, row_hi, c->d_ids + ids_offset, ns, lr, bs_mode);
 }
 
 int f2v_flush(f2v_handle c) {
@@ -726,6 +756,7 @@ int f2v_train(f2v_handle c, int option, uint32_t iters, uint32_t batch, uint32_t
     const bool all_upfront = (math != 7) && (per_epoch * iters * 4ull <= (1ull << 30));
     const uint64_t dev_ids = std::max<uint64_t>(all_upfront ? per_epoch * std::max(iters, 1u) : per_epoch, 64);
     if ((rc = reserve_ids(c, dev_ids)) != F2V_OK) return rc;
+    c->ids_valid = 0;
     std::vector<uint32_t> ids;
     auto draw_epoch = [&](std::vector<uint32_t> &v, size_t off) {
         for (uint32_t b = 0; b < nb; b++) {

@@ -68,18 +68,21 @@ class NcclStageComm:
         engine.stage_reserve(per * self.world)  # room for the padded all-gather
         self._stream = self.torch.cuda.ExternalStream(engine.stream(), device=self.device)
 
-    def _view(self, engine):
-        ptr, cap = engine.stage_device_ptr()
-        v = self._views.get(ptr)
+    def _matrix_view(self, engine, lo):
+        """torch view of the whole matrix the staged rows live in (two matrices alternate: two views, made once)."""
+        ptr, cap = engine.stage_device_ptr()          # address of staged row `lo`, rows available from there
+        base = ptr - lo * engine.dim * 4
+        v = self._views.get(base)
         if v is None:
-            v = self.torch.as_tensor(_DevBuf(ptr, cap * engine.dim), device=self.torch.device("cuda", self.device))
-            self._views[ptr] = v
+            v = self.torch.as_tensor(_DevBuf(base, (cap + lo) * engine.dim), device=self.torch.device("cuda", self.device))
+            self._views[base] = v
         return v
 
     def exchange(self, engine, lo, hi):
         per, _, _ = shard_bounds(lo, hi, self.rank, self.world)
-        full = self._view(engine)[: per * self.world * engine.dim]
-        mine = full[self.rank * per * engine.dim: (self.rank + 1) * per * engine.dim]
+        d = engine.dim
+        full = self._matrix_view(engine, lo)[lo * d: (lo + per * self.world) * d]
+        mine = full[self.rank * per * d: (self.rank + 1) * per * d]
         with self.torch.cuda.stream(self._stream):
             self.dist.all_gather_into_tensor(full, mine)
 
@@ -102,16 +105,22 @@ class ShardedTrainer:
             e.set_param("hub_chunk_for_batch", batch)  # same chunk as the single-GPU f2v_train, whatever the world size
         self.comm.prepare(e, min(batch, n))
         ndraw = ns * batch if bs_mode else ns
+        stride = (min(batch, n) + ns) if bs_mode else ns
         for _ in range(iters):
             if math == 7:
                 e.generate_walks()  # same stream on every rank: sample/algorithms.cpp:1097-1118
+            # the epoch's sample ids do not depend on the embeddings: draw them now (option 7 draws them after
+            # the walks, as the reference's rand() order has it) and keep them in HBM -- no sync per minibatch
+            ids = np.zeros(nb * stride, dtype=np.uint32)
+            for b in range(nb):
+                maxv = min((b + 1) * batch, n - 1) if math == 7 else n - 1  # algorithms.cpp:1125
+                keep = min(stride, ndraw)  # -bs 1 draws ns*BATCH ids of which rows+ns-1 are ever read
+                ids[b * stride: b * stride + keep] = e.draw_samples(maxv, ndraw, keep)
+            e.upload_sample_ids(ids)
             for b in range(nb):
                 lo, hi = b * batch, min((b + 1) * batch, n)
-                maxv = min((b + 1) * batch, n - 1) if math == 7 else n - 1  # algorithms.cpp:1125
-                keep = (hi - lo) + ns - 1 if bs_mode else ns
-                ids = e.draw_samples(maxv, ndraw, min(keep, ndraw))
                 _, my_lo, my_hi = shard_bounds(lo, hi, self.rank, self.world)
-                e.minibatch_step(option, lo, hi, ids, ns, lr, bs_mode, row_lo=my_lo, row_hi=my_hi)
+                e.minibatch_step_at(option, lo, hi, b * stride, ns, lr, bs_mode, row_lo=my_lo, row_hi=my_hi)
                 if self.world > 1 or self.exchange_when_single:
                     self.comm.exchange(e, lo, hi)
         e.flush()

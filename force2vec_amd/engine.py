@@ -95,6 +95,15 @@ class Engine:
                                          batch_lo if row_lo is None else row_lo, batch_hi if row_hi is None else row_hi,
                                          _u32(ids), len(ids), ns, lr, bs_mode))
 
+    def upload_sample_ids(self, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        check(self._L.f2v_upload_sample_ids(self._h, _u32(ids), len(ids)))
+
+    def minibatch_step_at(self, option, batch_lo, batch_hi, ids_offset, ns, lr, bs_mode=0, row_lo=None, row_hi=None):
+        check(self._L.f2v_minibatch_step_at(self._h, option, batch_lo, batch_hi,
+                                            batch_lo if row_lo is None else row_lo, batch_hi if row_hi is None else row_hi,
+                                            ids_offset, ns, lr, bs_mode))
+
     def flush(self):
         check(self._L.f2v_flush(self._h))
 

@@ -78,14 +78,21 @@ int f2v_train(f2v_handle h, int option, uint32_t iters, uint32_t batch, uint32_t
 /* One minibatch: the kgen row-kernel boundary Calc_<pre>frc_<tdist|sigmoid>_DIM<D>_VL<V>
  * (sample/kgen/genDimFrc.base:36-57) lifted to a batch, and the unit the multi-GPU driver
  * shards.  Computes the new embeddings of rows [row_lo,row_hi) of minibatch
- * [batch_lo,batch_hi) from the pre-batch matrix and keeps them in the staging buffer; they
- * become visible in the matrix when the next step / f2v_flush commits them (other ranks'
- * rows are merged first with f2v_stage_write).  sample_ids: host array of the minibatch's
+ * [batch_lo,batch_hi) from the pre-batch matrix into the epoch's second matrix ("staged": later
+ * minibatches read them there, f2v_flush / the end of the epoch makes them the matrix; other
+ * ranks' rows of the same minibatch are merged first with f2v_stage_write / an all-gather).  sample_ids: host array of the minibatch's
  * negative-sample vertex ids (ns of them, or (batch_hi-batch_lo)+ns-1 in bs_mode).
  * Option 7 uses the walks set by f2v_set_walks. */
 int f2v_minibatch_step(f2v_handle h, int option, uint32_t batch_lo, uint32_t batch_hi, uint32_t row_lo,
                        uint32_t row_hi, const uint32_t *sample_ids, uint32_t n_sample_ids, uint32_t ns, float lr,
                        int bs_mode);
+/* The same step with the sample ids already in HBM: f2v_upload_sample_ids copies a host array (e.g. one
+ * epoch's ids, drawn up-front: they do not depend on the embeddings) once, f2v_minibatch_step_at names the
+ * minibatch's ids by their offset in it.  No host-device synchronisation per step: the multi-GPU driver
+ * enqueues step and exchange back to back. */
+int f2v_upload_sample_ids(f2v_handle h, const uint32_t *ids, uint64_t count);
+int f2v_minibatch_step_at(f2v_handle h, int option, uint32_t batch_lo, uint32_t batch_hi, uint32_t row_lo,
+                          uint32_t row_hi, uint64_t ids_offset, uint32_t ns, float lr, int bs_mode);
 /* Commit the staged minibatch into the matrix (K5, sample/algorithms.cpp:629-639 / 913-921). */
 int f2v_flush(f2v_handle h);
 /* Option 7 walk samples of the current epoch, uint32[5*n] (sample/algorithms.cpp:1097-1118). */
@@ -98,8 +105,9 @@ int f2v_rand_index(f2v_handle h, uint32_t max_num, uint32_t min_num, uint32_t *o
  * (One minibatch's sample loop, sample/algorithms.cpp:577-586; -bs 1 draws ns*BATCH, :686.) */
 int f2v_rand_indices(f2v_handle h, uint32_t max_num, uint32_t min_num, uint64_t count, uint64_t keep, uint32_t *out);
 
-/* Multi-GPU exchange: device address of the staged rows of the pending minibatch (row r of
- * the batch at float offset (r-batch_lo)*dim), the number of rows it can hold, and a host
+/* Multi-GPU exchange: device address of the staged rows of the last stepped minibatch (row r of the
+ * batch at float offset (r-batch_lo)*dim; it points into the second matrix), the number of rows that may
+ * be written from there (the matrix has slack behind row N for a padded all-gather), and a host
  * read/write of a row range of it (gloo / test path). */
 int f2v_stage_device_ptr(f2v_handle h, uint64_t *devptr_out, uint32_t *capacity_rows_out);
 int f2v_stage_read(f2v_handle h, uint32_t row_lo, uint32_t row_hi, float *out);

@@ -58,6 +58,13 @@ class OracleEngine:
         rows[row_lo - lo: row_hi - lo] = work[row_lo:row_hi]
         self.pending = (lo, hi, rows)
 
+    def upload_sample_ids(self, ids):
+        self.ids = np.array(ids, dtype=np.uint32)
+
+    def minibatch_step_at(self, option, lo, hi, ids_offset, ns, lr, bs_mode=0, row_lo=None, row_hi=None):
+        need = (hi - lo) + ns - 1 if bs_mode else ns
+        self.minibatch_step(option, lo, hi, self.ids[ids_offset: ids_offset + need], ns, lr, bs_mode, row_lo, row_hi)
+
     def stage_read(self, row_lo, row_hi):
         lo, hi, rows = self.pending
         return rows[row_lo - lo: row_hi - lo].copy()
