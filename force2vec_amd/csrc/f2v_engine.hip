@@ -339,7 +339,6 @@ int launch_step(f2v_ctx *c, int math, uint32_t batch_lo, uint32_t batch_hi, uint
         f.items = c->d_hubs + plan.fin_off[lev];
         f.n_items = plan.fin_cnt[lev];
         f.D = c->D;
-        f.batch_lo = batch_lo;
         const uint32_t fb = (f.n_items + 3) / 4;
         rc = dispatch_layout(c, [&](auto V, auto E) {
             constexpr int VEC = decltype(V)::value;

@@ -88,7 +88,6 @@ struct FinalizeArgs {
     const FinItem *items;
     uint32_t n_items;
     uint32_t D;
-    uint32_t batch_lo;
 };
 
 // ---- cross-lane primitives -------------------------------------------------------------------

@@ -419,7 +419,7 @@ int orc_minibatch(int option, int bs_mode, const uint32_t *rowptr, const uint32_
             row_sigmoid(X, D, i, colids + rowptr[i], gdeg, gdeg, S, ns, lr, table, order, chunk, out);
         else if (option == 7)
             row_sigmoid(X, D, i, walks + (size_t)i * ORC_WALKLENGTH, ORC_WALKLENGTH, gdeg, S, ns, lr,
-                        table, order, chunk, out);
+                        table, order, 0 /* the 5 walk samples are never split */, out);
         else { free(snap); free(newrows); free((void *)S); return -2; }
     }
     for (uint32_t i = row_lo; i < row_hi; i++)
@@ -510,7 +510,7 @@ int orc_row(int option, const uint32_t *rowptr, const uint32_t *colids, uint32_t
         row_sigmoid(X, D, i, colids + rowptr[i], gdeg, gdeg, S, ns, lr, table, order, chunk, out);
     else if (option == 7)
         row_sigmoid(X, D, i, walks + (size_t)i * ORC_WALKLENGTH, ORC_WALKLENGTH, gdeg, S, ns, lr, table,
-                    order, chunk, out);
+                    order, 0, out);
     else
         rc = -2;
     free((void *)S);

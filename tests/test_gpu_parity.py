@@ -134,6 +134,60 @@ def test_hub_combine_tree(F, option, fanin):
         eng.close()
 
 
+def _csr(n, edges):
+    r = np.array([e[0] for e in edges], dtype=np.int64)
+    c = np.array([e[1] for e in edges], dtype=np.int64)
+    order = np.lexsort((c, r))
+    rowptr = np.zeros(n + 1, dtype=np.uint32)
+    if len(edges):
+        rowptr[1:] = np.cumsum(np.bincount(r, minlength=n))
+    return rowptr, c[order].astype(np.uint32)
+
+
+EDGE_GRAPHS = {
+    "two_vertices": (2, [(0, 1), (1, 0)]),
+    "no_edges": (7, []),
+    "self_loops_and_duplicates": (5, [(0, 0), (0, 1), (0, 1), (1, 0), (2, 2), (3, 4), (4, 3), (4, 3), (4, 4)]),  # a general (unsymmetric) matrix keeps both
+    "star": (40, [(0, k) for k in range(1, 40)] + [(k, 0) for k in range(1, 40)]),
+    "directed_chain": (9, [(k, k + 1) for k in range(8)]),
+}
+
+
+@pytest.mark.parametrize("gname", sorted(EDGE_GRAPHS))
+@pytest.mark.parametrize("option,dim,batch,ns,bs", [(5, 128, 3, 5, 0), (5, 1, 1, 1, 0), (5, 512, 64, 0, 0), (6, 64, 2, 3, 1),
+                                                     (6, 7, 100, 5, 0), (7, 128, 4, 2, 0), (5, 33, 5, 4, 1)])
+def test_edge_case_graphs_and_shapes(F, gname, option, dim, batch, ns, bs):
+    """Ragged and degenerate inputs: N = 2, no edges at all, self-loops and duplicate entries, a star (one hub),
+    a directed chain; D from 1 to 512 (both kernel layouts, exact and masked), batch 1 ... > N, ns = 0, -bs 1."""
+    n, edges = EDGE_GRAPHS[gname]
+    rowptr, colids = _csr(n, edges)
+    if option == 7 and len(colids) == 0:
+        pytest.skip("option 7 walks index colids[] even for isolated vertices: undefined on an edgeless graph (reference too)")
+    rng = np.random.default_rng(len(edges) + dim)
+    X0 = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    eng = F.Engine(rowptr, colids, dim)
+    eng.set_param("hub_chunk", 4)
+    eng.set_embeddings(X0)
+    Xo = X0.copy()
+    orng = O.Rng(5)
+    for epoch in range(3):
+        walks = None
+        if option == 7:
+            walks = O.generate_walks(orng, rowptr, colids)
+            eng.set_walks(walks)
+        for lo in range(0, n, batch):
+            hi = min(lo + batch, n)
+            nid = (hi - lo) + ns - 1 if bs else ns
+            ids = rng.integers(0, n - 1, max(nid, 0)).astype(np.uint32)
+            eng.minibatch_step(option, lo, hi, ids, ns, 0.02, bs)
+            if nid > 0 or not bs:
+                O.minibatch(option, rowptr, colids, Xo, lo, hi, ids if nid > 0 else np.zeros(1, np.uint32), ns, 0.02, bs_mode=bs,
+                            walks=walks, order=O.ORDER_TREE, chunk=4)
+    got = eng.get_embeddings()
+    assert np.array_equal(got, Xo), float(np.nanmax(np.abs(got - Xo)))
+    eng.close()
+
+
 def test_sharded_rows_and_stage_exchange(F):
     """The multi-GPU unit: two engines each compute half of every minibatch and exchange staged rows."""
     n, dim, batch = 260, 128, 100
