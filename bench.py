@@ -133,6 +133,7 @@ def main():
     ap.add_argument("--cpu-scale", type=int, default=17)
     ap.add_argument("--cpu-iters", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="drive even a single rank through the multi-GPU path (RCCL group of 1): self-test")
     ap.add_argument("--extra-batches", type=str, default="256,4096,16384", help="comma list of further batch sizes to time (reported under 'extra')")
     args = ap.parse_args()
 
@@ -149,8 +150,13 @@ def main():
 
     dist = None
     torch = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -169,18 +175,23 @@ def main():
 
     def barrier():
         eng.synchronize()
-        if world > 1:
+        if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
 
     def run_epochs(k, batch):
-        if world == 1:
+        """-> per-rank statistics of these k epochs (launches, algorithmic bytes, device seconds where known)."""
+        if not use_dist:
             eng.train(args.option, k, batch, 5, 0.02, 0)
             return eng.stats()
+        s0 = eng.stats()
         comm = fdist.NcclStageComm(dist, rank, world, local_rank)
-        fdist.ShardedTrainer(eng, rank, world, comm).train(args.option, k, batch, 5, 0.02, 0)
-        return None
+        fdist.ShardedTrainer(eng, rank, world, comm, exchange_when_single=True).train(args.option, k, batch, 5, 0.02, 0)
+        s1 = eng.stats()
+        st = {key: s1[key] - s0[key] for key in s1}
+        st["device_seconds"] = None  # the sharded loop is timed by the wall clock below
+        return st
 
     def timed(k, w, batch):
         if w > 0:
@@ -190,7 +201,7 @@ def main():
         st = run_epochs(k, batch)
         barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -209,17 +220,18 @@ def main():
                    "parallelism": "1 GPU" if world == 1 else "minibatch rows sharded over %d GPUs, replicated graph+matrix, RCCL all-gather of staged rows" % world},
     }
     if st is not None:
-        # dominant kernel = step_kernel, one launch per minibatch; launch time from HIP events on the
-        # engine's stream around the epoch loop (f2v_train), algorithmic bytes per SURVEY 8d
+        # dominant kernel = qstep_kernel, one launch per minibatch; launch time from HIP events on the
+        # engine's stream around the epoch loop (f2v_train), algorithmic bytes per SURVEY 8d.
+        # N > 1: rank 0's share of the bytes over the wall time of the sharded loop (exchange included).
         per_launch = st["algorithmic_bytes"] / max(st["step_launches"], 1)
-        t_launch = st["device_seconds"] / max(st["step_launches"], 1)
+        t_launch = (st["device_seconds"] if st["device_seconds"] else dt) / max(st["step_launches"], 1)
         ach = per_launch / t_launch * 1e-9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
             try:
                 tj = json.load(open(tp))
-                if tj.get("batch") == args.batch and tj.get("scale") == args.scale and tj.get("dim") == args.dim:
+                if not use_dist and tj.get("batch") == args.batch and tj.get("scale") == args.scale and tj.get("dim") == args.dim:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 pass
@@ -241,7 +253,7 @@ def main():
             except Exception as ex:  # the baseline is reported, never required for the GPU number
                 res["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": os.cpu_count(), "kind": "reference", "sample": "failed: %r" % (ex,)}
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
