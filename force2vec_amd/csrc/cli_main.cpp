@@ -35,6 +35,7 @@ static void helpmessage() {
     printf("-bs <int>, 1 = draw nsamples*batch negative samples per minibatch (options 5 and 6).\n");
     printf("-device <int>, HIP device ordinal. (default:0)\n");
     printf("-seed <int>, srand() seed. (default:1)\n");
+    printf("-fastrng <int>, 1 = NON-PARITY fast mode: initial embeddings and option-7 walks from a device-side RNG.\n");
     printf("-cache <int>, 1 = keep / reuse the binary CSR <input>.f2vcsr (an input ending in .f2vcsr is read directly).\n");
     printf("-binout <int>, 1 = also write <output file>.bin, raw fp32 N x D (the scorers' binary embedding format).\n");
     printf("-h, show help message.\n");
@@ -45,7 +46,7 @@ static int TestAlgorithms(int argc, char *argv[]) {
     INDEXTYPE batchsize = 384, iterations = 1200, numberOfThreads = std::thread::hardware_concurrency(), dim = 128, option = 5, nsamples = 5;
     string inputfile = "", outputfile = "", algoname = "Force2Vec:t-distribution with negative sampling", initname = "RAND";
     INDEXTYPE bs = 0;
-    int device = 0, cache = 0, binout = 0;
+    int device = 0, cache = 0, binout = 0, fastrng = 0;
     unsigned seed = 1;
     for (int p = 0; p < argc; p++) {
         const bool has_val = p + 1 < argc;
@@ -65,6 +66,7 @@ static int TestAlgorithms(int argc, char *argv[]) {
         else if (strcmp(argv[p], "-device") == 0) device = atoi(argv[p + 1]);
         else if (strcmp(argv[p], "-seed") == 0) seed = (unsigned)atoi(argv[p + 1]);
         else if (strcmp(argv[p], "-cache") == 0) cache = atoi(argv[p + 1]);
+        else if (strcmp(argv[p], "-fastrng") == 0) fastrng = atoi(argv[p + 1]);
         else if (strcmp(argv[p], "-binout") == 0) binout = atoi(argv[p + 1]);
         else if (strcmp(argv[p], "-lr") == 0) lr = atof(argv[p + 1]);
         else if (strcmp(argv[p], "-nsamples") == 0) nsamples = atoi(argv[p + 1]);
@@ -97,6 +99,7 @@ static int TestAlgorithms(int argc, char *argv[]) {
         SetInputMatricesAsCSR(A_csr, inputfile, cache != 0);
         algorithms algo(A_csr, inputfile, outputfile, dim, gamma, batchsize, device);
         algo.binary_output = binout != 0;
+        if (fastrng && f2v_set_param(algo.h, "fast_rng", 1) != F2V_OK) throw std::runtime_error(f2v_last_error());
         algo.srand(seed);
         cout << "Running: " << algoname << endl;
         if (option == 5) outputvec = bs == 0 ? algo.AlgoForce2VecNS(iterations, numberOfThreads, batchsize, nsamples, lr)

@@ -75,6 +75,8 @@ struct f2v_ctx {
     bool pending = false;             // a minibatch has been stepped since the last flush
     uint32_t p_lo = 0, p_hi = 0;      // ... and this is it (multi-GPU exchange window)
     int waves_per_block = 4;
+    bool fast_rng = false;        // non-parity mode: device-side init and option-7 walks (counter-based RNG)
+    uint64_t fast_seed = 1, fast_epoch = 0;
     int rows_in_flight = 4;
     f2v_stats stats{};
 };
@@ -457,6 +459,8 @@ int f2v_destroy(f2v_handle c) {
 int f2v_srand(f2v_handle c, uint32_t seed) {
     if (!c) return fail(F2V_EINVAL, "null handle");
     c->rng.seed(seed);
+    c->fast_seed = seed;
+    c->fast_epoch = 0;
     return F2V_OK;
 }
 
@@ -480,6 +484,16 @@ int f2v_init_embeddings(f2v_handle c, int kind) {
     if (kind != F2V_INIT_SYMMETRIC && kind != F2V_INIT_UNIT) return fail(F2V_EINVAL, "f2v_init_embeddings: kind %d", kind);
     HIPC(hipSetDevice(c->device));
     const size_t total = (size_t)c->n * c->D;
+    if (c->fast_rng) {  // non-parity: hash-based uniform values generated in HBM
+        HIPC(hipStreamSynchronize(c->stream));
+        c->pending = false;
+        c->upd_lo = c->upd_hi = 0;
+        hipLaunchKernelGGL(fast_init_kernel, dim3(4096), dim3(256), 0, c->stream, c->d_X[c->cur], (uint64_t)total, kind, c->fast_seed * 0x9E3779B97F4A7C15ull + 17);
+        HIPC(hipGetLastError());
+        HIPC(hipStreamSynchronize(c->stream));
+        c->have_x = true;
+        return F2V_OK;
+    }
     std::vector<float> x(total);
     init_embeddings_host(c->rng, x.data(), total, kind);
     HIPC(hipStreamSynchronize(c->stream));
@@ -551,6 +565,10 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
         c->use_quarter = value != 0;
         return F2V_OK;
     }
+    if (!strcmp(name, "fast_rng")) {
+        c->fast_rng = value != 0;
+        return F2V_OK;
+    }
     if (!strcmp(name, "rows_in_flight")) {
         if (value != 4 && value != 8) return fail(F2V_EINVAL, "rows_in_flight must be 4 or 8");
         c->rows_in_flight = (int)value;
@@ -570,6 +588,7 @@ int f2v_get_param(f2v_handle c, const char *name, int64_t *out) {
     if (!strcmp(name, "waves_per_block")) { *out = c->waves_per_block; return F2V_OK; }
     if (!strcmp(name, "quarter_wave")) { *out = c->use_quarter ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "hub_fanin")) { *out = c->fanin; return F2V_OK; }
+    if (!strcmp(name, "fast_rng")) { *out = c->fast_rng ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "hub_chunk_auto")) { *out = c->chunk_auto ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "dim")) { *out = c->D; return F2V_OK; }
     if (!strcmp(name, "n")) { *out = c->n; return F2V_OK; }
@@ -591,8 +610,29 @@ int f2v_set_walks(f2v_handle c, const uint32_t *walks) {
     return F2V_OK;
 }
 
+// non-parity walks generated in HBM (see fast_walks_kernel)
+static int fast_walks(f2v_ctx *c) {
+    const size_t cnt = (size_t)c->n * kWalkLength;
+    if (!c->d_walks) HIPC(hipMalloc((void **)&c->d_walks, cnt * sizeof(uint32_t)));
+    hipLaunchKernelGGL(fast_walks_kernel, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, c->d_rowptr, c->d_colids, c->n, c->nnz,
+                       c->d_walks, c->fast_seed * 0xD1342543DE82EF95ull + 5, c->fast_epoch++);
+    HIPC(hipGetLastError());
+    c->have_walks = true;
+    return F2V_OK;
+}
+
 int f2v_generate_walks(f2v_handle c, uint32_t *walks_out) {
     if (!c) return fail(F2V_EINVAL, "null handle");
+    if (c->fast_rng) {
+        HIPC(hipSetDevice(c->device));
+        int rc = fast_walks(c);
+        if (rc != F2V_OK) return rc;
+        if (walks_out) {
+            HIPC(hipStreamSynchronize(c->stream));
+            HIPC(hipMemcpy(walks_out, c->d_walks, (size_t)c->n * kWalkLength * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        }
+        return F2V_OK;
+    }
     std::vector<uint32_t> w;
     generate_walks_host(c, w);
     if (walks_out) memcpy(walks_out, w.data(), w.size() * sizeof(uint32_t));
@@ -752,7 +792,7 @@ int f2v_train(f2v_handle c, int option, uint32_t iters, uint32_t batch, uint32_t
     if ((rc = upload_plans(c)) != F2V_OK) return rc;
     // Sample ids do not depend on the embeddings: options 5/6 pre-draw every epoch's ids (as long
     // as that stays below 1 GiB); option 7 interleaves walk generation, so it goes epoch by epoch.
-    const bool all_upfront = (math != 7) && (per_epoch * iters * 4ull <= (1ull << 30));
+    const bool all_upfront = (math != 7 || c->fast_rng) && (per_epoch * iters * 4ull <= (1ull << 30));
     const uint64_t dev_ids = std::max<uint64_t>(all_upfront ? per_epoch * std::max(iters, 1u) : per_epoch, 64);
     if ((rc = reserve_ids(c, dev_ids)) != F2V_OK) return rc;
     c->ids_valid = 0;
@@ -784,7 +824,9 @@ int f2v_train(f2v_handle c, int option, uint32_t iters, uint32_t batch, uint32_t
     HIPC(hipEventRecord(ev0, c->stream));
     std::vector<uint32_t> walks;
     for (uint32_t it = 0; it < iters; it++) {
-        if (math == 7) {
+        if (math == 7 && c->fast_rng) {
+            if ((rc = fast_walks(c)) != F2V_OK) return rc;  // stream-ordered: no host work, no synchronisation
+        } else if (math == 7) {
             generate_walks_host(c, walks);
             if (!c->d_walks) HIPC(hipMalloc((void **)&c->d_walks, walks.size() * sizeof(uint32_t)));
             HIPC(hipStreamSynchronize(c->stream));  // previous epoch's steps read d_walks / d_ids

@@ -553,6 +553,47 @@ __global__ __launch_bounds__(256) void commit_kernel(float *X, const float *Xn, 
     }
 }
 
+// ---- non-parity fast mode: counter-based RNG on the device ---------------------------
+// The reference's libc rand() stream is inherently serial (and, for the option-7 walks, its consumption is
+// data dependent), so the parity path draws it on the host.  For very large N that costs seconds per run
+// (init) or bounds the epoch (walks).  The fast mode replaces both with a stateless hash of
+// (seed, stream, index): same distributions, different numbers -- it is NOT bit-comparable with the
+// reference and is off unless "fast_rng" is set.
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// X[k] = U[-1,1) (kind 0) or U[0,1) (kind 1) with 24 random bits, as randInitF / randInit distribute
+__global__ void fast_init_kernel(float *X, uint64_t total, int kind, uint64_t seed) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += stride) {
+        const float u = (float)(mix64(seed ^ (k * 0xD6E8FEB86659FD93ull)) >> 40) * (1.0f / 16777216.0f);
+        X[k] = kind == 0 ? -1.0f + 2.0f * u : u;
+    }
+}
+
+// One thread per vertex: the 5-step semi-random walk of sample/algorithms.cpp:1097-1118 -- a uniformly random
+// neighbour except the last one if deg > 2, the first neighbour if deg == 2, otherwise colids[w] with the
+// vertex id as edge index (the reference's quirk, clamped to the array).
+__global__ void fast_walks_kernel(const uint32_t *rowptr, const uint32_t *colids, uint32_t n, uint64_t nnz, uint32_t *walks,
+                                  uint64_t seed, uint64_t epoch) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t w = i;
+    for (uint32_t s = 0; s < 5; ++s) {
+        const uint32_t rp = rowptr[w], deg = rowptr[w + 1] - rp;
+        uint64_t j = w;
+        if (deg > 2) j = rp + mix64(seed ^ mix64(epoch * 0x100000001B3ull + (uint64_t)i * 5u + s)) % (deg - 1);
+        else if (deg == 2) j = rp;
+        if (j >= nnz) j = nnz ? nnz - 1 : 0;
+        w = colids[j];
+        walks[(size_t)i * 5u + s] = w;
+    }
+}
+
 // PMC calibration: the step kernel's access pattern with a KNOWN byte count.  Every quarter-wave
 // gathers whole 64*NB-float rows (NB x 16 lanes x dwordx4) named by `ids`, each row exactly once,
 // and folds them into a checksum so that the loads stay live.

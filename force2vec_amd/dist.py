@@ -8,7 +8,7 @@ and ONE exchange per minibatch -- an all-gather of the staged new rows, B x D fp
 makes every replica identical again.  Results are bit-identical to the single-GPU run for any
 world size.  Every rank draws the same rand() stream on its host.
 
-The exchange is an in-place RCCL all-gather on the staging buffer (torch.distributed backend
+The exchange is an in-place RCCL all-gather on those rows of the second matrix (torch.distributed backend
 "nccl", zero-copy on the engine's own HIP stream); a host-bounce variant serves gloo."""
 import numpy as np
 
@@ -55,7 +55,7 @@ class _DevBuf:
 
 
 class NcclStageComm:
-    """In-place RCCL all-gather over xGMI on the engine's staging buffer and HIP stream."""
+    """In-place RCCL all-gather over xGMI on the new rows inside the engine's second matrix, on its HIP stream."""
 
     def __init__(self, dist, rank, world, device):
         import torch

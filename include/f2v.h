@@ -59,7 +59,11 @@ int f2v_get_embeddings(f2v_handle h, float *x_out);
  * reference's summation order for every row; unset = chosen from the batch size by f2v_train, or
  * by setting "hub_chunk_for_batch" = B); "hub_fanin": fan-in of the tree that adds a split row's
  * partial sums (0 = one sequential pass); "quarter_wave": 0 selects the one-item-per-wavefront
- * kernel for every D; "waves_per_block".  f2v_get_param also answers "dim", "n", "nnz". */
+ * kernel for every D; "waves_per_block"; "rows_in_flight" (4|8).
+ * "fast_rng" = 1 selects the NON-PARITY fast mode: initial embeddings and the option-7
+ * walks are generated on the device by a counter-based RNG (same distributions, different numbers than
+ * the reference's libc rand() stream); negative-sample ids still come from the handle's rand() stream.
+ * f2v_get_param also answers "dim", "n", "nnz". */
 int f2v_set_param(f2v_handle h, const char *name, int64_t value);
 int f2v_get_param(f2v_handle h, const char *name, int64_t *value_out);
 

@@ -368,3 +368,57 @@ def test_cora_f1_within_half_point_of_reference(F, manifest):
         assert abs(mic - r["micro"]) <= 0.5, (tf, mic, r["micro"])
         assert abs(mac - r["macro"]) <= 0.75, (tf, mac, r["macro"])
     algo.engine.close()
+
+
+def test_fast_rng_mode_is_statistically_equivalent(F, manifest):
+    """The NON-parity fast mode (device-side init and option-7 walks): right distributions,
+    valid walks, reproducible per seed, and node-classification F1 on Cora level with the parity mode."""
+    import f1_harness as H
+    rowptr, colids = F.read_mtx(golden_graph_path("cora.mtx"))
+    n = len(rowptr) - 1
+    deg = np.diff(rowptr.astype(np.int64))
+    eng = F.Engine(rowptr, colids, 128)
+    eng.set_param("fast_rng", 1)
+    eng.srand(1)
+    eng.init_embeddings(0)
+    X = eng.get_embeddings()
+    assert X.min() >= -1.0 and X.max() < 1.0 and abs(X.mean()) < 5e-3 and abs(X.var() - 1 / 3) < 5e-3
+    eng.init_embeddings(1)
+    U = eng.get_embeddings()
+    assert U.min() >= 0.0 and U.max() < 1.0 and abs(U.mean() - 0.5) < 5e-3
+    eng.srand(1)
+    eng.init_embeddings(0)
+    assert np.array_equal(eng.get_embeddings(), X)          # same seed -> same matrix
+    eng.srand(2)
+    eng.init_embeddings(0)
+    assert not np.array_equal(eng.get_embeddings(), X)
+    w = eng.generate_walks().reshape(n, 5)
+    w2 = eng.generate_walks().reshape(n, 5)
+    assert not np.array_equal(w, w2)                        # a new epoch draws new walks
+    prev = np.arange(n)
+    for s in range(5):
+        for i in range(0, n, 7):
+            p, nxt = prev[i], w[i, s]
+            nb = colids[rowptr[p]:rowptr[p + 1]]
+            if deg[p] > 2:
+                assert nxt in nb[:-1] or (nxt == nb[-1] and nb[-1] in nb[:-1])   # never the last entry (duplicates aside)
+            elif deg[p] == 2:
+                assert nxt == nb[0]
+            else:
+                assert nxt == colids[min(p, len(colids) - 1)]
+        prev = w[:, s]
+    eng.close()
+    labels = H.load_labels(os.path.join(GOLD, "cora.nodes.labels"), n)
+    ref = manifest["f1_reference_cora_opt5_it1200_B256_D128"]
+    scores = {}
+    for option, fast in ((5, 1), (7, 0), (7, 1)):
+        a = F.algorithms((rowptr, colids), dim=128)
+        a.engine.set_param("fast_rng", fast)
+        a.srand(1)
+        a._run(option, 0, 1200 if option == 5 else 300, 256, 5, 0.02, write=False)
+        scores[(option, fast)] = H.f1_scores(a.nCoordinates, labels, n_splits=5)
+        a.engine.close()
+    for tf, (mic, _) in scores[(5, 1)].items():                      # option 5 from a hash-based init
+        assert abs(mic - ref["%.2f" % tf]["micro"]) <= 1.5, (tf, mic)
+    for tf in scores[(7, 0)]:                                         # option 7: device walks vs the reference's walks
+        assert abs(scores[(7, 1)][tf][0] - scores[(7, 0)][tf][0]) <= 2.5, (tf, scores[(7, 1)][tf], scores[(7, 0)][tf])
