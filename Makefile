@@ -5,7 +5,7 @@ ARCH ?= gfx950
 CSRC = force2vec_amd/csrc
 # -ffp-contract=off: the reference's mul/add pairs are separate roundings (x86-64 without FMA);
 # parity with the oracle depends on it.
-CXXFLAGS = -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result
+CXXFLAGS = -O3 -std=c++17 -fPIC -pthread -Iinclude -I$(CSRC) -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result
 HIPFLAGS = --offload-arch=$(ARCH) $(CXXFLAGS)
 LIB = force2vec_amd/libf2v.so
 

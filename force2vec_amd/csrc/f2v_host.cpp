@@ -2,13 +2,18 @@
 // reference draws from, MatrixMarket ingest into CSR, the .embd writer and file naming,
 // the sigmoid table.  No device code here; see f2v_engine.hip for the HBM side.
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "f2v.h"
@@ -97,15 +102,22 @@ int f2v_read_mtx(const char *path, uint32_t *n_out, uint64_t *nnz_out, uint32_t 
     if (!path || !n_out || !nnz_out || !rowptr_out || !colids_out) return fail(F2V_EINVAL, "f2v_read_mtx: null argument");
     FILE *fp = fopen(path, "rb");
     if (!fp) return fail(F2V_EIO, "f2v_read_mtx: cannot open %s: %s", path, strerror(errno));
-    // slurp: the parse below is a single pass over memory (fast path for 10^8-edge files)
+    // slurp: the parse below works on memory (fast path for 10^8-edge files)
+    const bool trace = getenv("F2V_IO_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = now();
+    auto lap = [&](const char *what) {
+        if (trace) { const double t = now(); fprintf(stderr, "f2v_read_mtx: %-22s %.3f s\n", what, t - t_prev); t_prev = t; }
+    };
     fseek(fp, 0, SEEK_END);
     long fsz = ftell(fp);
     fseek(fp, 0, SEEK_SET);
-    std::vector<char> buf((size_t)fsz + 1);
-    size_t got = fread(buf.data(), 1, (size_t)fsz, fp);
+    std::unique_ptr<char[]> buf(new char[(size_t)fsz + 1]);
+    size_t got = fread(buf.get(), 1, (size_t)fsz, fp);
     fclose(fp);
     buf[got] = 0;
-    const char *p = buf.data(), *end = buf.data() + got;
+    lap("read file");
+    const char *p = buf.get(), *end = buf.get() + got;
     static const char kSym[] = "symmetric";
     bool symmetric = false;
     while (p < end && *p == '%') {
@@ -130,41 +142,111 @@ int f2v_read_mtx(const char *path, uint32_t *n_out, uint64_t *nnz_out, uint32_t 
     if (!parse_uint(m) || !parse_uint(n) || !parse_uint(nz)) return fail(F2V_EIO, "f2v_read_mtx: %s: bad size line", path);
     skip_line();
     if (m >= 0xFFFFFFFFull) return fail(F2V_EINVAL, "f2v_read_mtx: %llu rows exceed 32-bit vertex ids", (unsigned long long)m);
-    std::vector<uint32_t> rows, cols;
-    rows.reserve((size_t)nz * (symmetric ? 2 : 1));
-    cols.reserve((size_t)nz * (symmetric ? 2 : 1));
-    for (uint64_t k = 0; k < nz && p < end; k++) {
-        uint64_t r, c;
-        if (!parse_uint(r) || !parse_uint(c)) { skip_line(); continue; }
-        skip_line();
-        if (r == 0 || c == 0 || r > m || c > m) return fail(F2V_EIO, "f2v_read_mtx: %s: entry %llu out of range", path, (unsigned long long)k);
-        uint32_t ri = (uint32_t)(r - 1), ci = (uint32_t)(c - 1);
-        if (symmetric) {
-            if (ri == ci) continue;
-            rows.push_back(ri); cols.push_back(ci);
-            rows.push_back(ci); cols.push_back(ri);
-        } else {
-            rows.push_back(ri); cols.push_back(ci);
+
+    // ---- parallel parse: the entry lines are cut into T byte ranges at line boundaries; every thread turns its
+    // lines into (row, col) pairs (kSkip for a line that does not start with two integers, as the serial rule).
+    const char *body = p;
+    const size_t body_len = (size_t)(end - body);
+    unsigned T = std::thread::hardware_concurrency();
+    if (const char *e = getenv("F2V_IO_THREADS")) T = (unsigned)atoi(e);
+    T = std::max(1u, std::min(T, 64u));
+    if (body_len < (8u << 20)) T = 1;
+    constexpr uint32_t kSkip = 0xFFFFFFFFu;
+    struct Part { std::vector<uint32_t> r, c; uint64_t bad_line = ~0ull; };
+    std::vector<Part> parts(T);
+    std::vector<const char *> cut(T + 1);
+    cut[0] = body;
+    cut[T] = end;
+    for (unsigned t = 1; t < T; t++) {
+        const char *q = body + body_len * t / T;
+        const char *eol = (const char *)memchr(q, '\n', (size_t)(end - q));
+        cut[t] = eol ? eol + 1 : end;
+    }
+    for (unsigned t = 1; t <= T; t++) cut[t] = std::max(cut[t], cut[t - 1]);
+    auto parse_range = [&](unsigned t) {
+        const char *q = cut[t], *qe = cut[t + 1];
+        Part &P = parts[t];
+        P.r.reserve((size_t)(qe - q) / 12 + 16);
+        P.c.reserve((size_t)(qe - q) / 12 + 16);
+        auto num = [&](uint64_t &v) -> bool {
+            while (q < qe && (*q == ' ' || *q == '\t' || *q == '\r')) q++;
+            if (q >= qe || *q < '0' || *q > '9') return false;
+            uint64_t x = 0;
+            while (q < qe && *q >= '0' && *q <= '9') x = x * 10 + (uint64_t)(*q++ - '0');
+            v = x;
+            return true;
+        };
+        while (q < qe) {
+            uint64_t r = 0, c = 0;
+            const bool ok = num(r) && num(c);
+            const char *eol = (const char *)memchr(q, '\n', (size_t)(qe - q));
+            q = eol ? eol + 1 : qe;
+            if (!ok) { P.r.push_back(kSkip); P.c.push_back(kSkip); continue; }
+            if (r == 0 || c == 0 || r > m || c > m) { if (P.bad_line == ~0ull) P.bad_line = P.r.size(); P.r.push_back(kSkip); P.c.push_back(kSkip); continue; }
+            P.r.push_back((uint32_t)(r - 1));
+            P.c.push_back((uint32_t)(c - 1));
         }
-    }
-    const size_t cnt = rows.size();
+    };
+    auto run_parallel = [&](unsigned nthreads, const std::function<void(unsigned)> &fn) {
+        if (nthreads <= 1) { fn(0); return; }
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nthreads; t++) th.emplace_back(fn, t);
+        fn(0);
+        for (auto &x : th) x.join();
+    };
+    run_parallel(T, parse_range);
+    lap("parse");
+    // only the first nz lines count (IO.h:108: `while (!eof && cnz < nnz)`); an out-of-range id among them is an error
+    std::vector<uint64_t> line0(T + 1, 0);
+    for (unsigned t = 0; t < T; t++) line0[t + 1] = line0[t] + parts[t].r.size();
+    for (unsigned t = 0; t < T; t++)
+        if (parts[t].bad_line != ~0ull && line0[t] + parts[t].bad_line < nz)
+            return fail(F2V_EIO, "f2v_read_mtx: %s: entry %llu out of range", path, (unsigned long long)(line0[t] + parts[t].bad_line));
+    // ---- CSR: per-row counts, scatter into the row buckets, sort every row -- all over row-disjoint or atomic slots
     uint32_t *rowptr = (uint32_t *)calloc((size_t)m + 1, sizeof(uint32_t));
-    uint32_t *colids = (uint32_t *)malloc((cnt ? cnt : 1) * sizeof(uint32_t));
-    if (!rowptr || !colids) { free(rowptr); free(colids); return fail(F2V_ENOMEM, "f2v_read_mtx: out of memory"); }
-    if (cnt >= 0xFFFFFFFFull) { free(rowptr); free(colids); return fail(F2V_EINVAL, "f2v_read_mtx: nnz exceeds 32-bit row pointers"); }
-    // two stable counting passes: by column, then by row  =>  (row, col) ascending, duplicates kept
-    const size_t ncols = (size_t)m;  // every column id is a vertex id (< rows), checked above
-    std::vector<uint32_t> cnt_c(ncols + 1, 0), order(cnt);
-    for (size_t k = 0; k < cnt; k++) cnt_c[cols[k] + 1]++;
-    for (size_t c = 0; c < ncols; c++) cnt_c[c + 1] += cnt_c[c];
-    for (size_t k = 0; k < cnt; k++) order[cnt_c[cols[k]]++] = (uint32_t)k;
-    for (size_t k = 0; k < cnt; k++) rowptr[rows[k] + 1]++;
-    for (size_t i = 0; i < m; i++) rowptr[i + 1] += rowptr[i];
-    std::vector<uint32_t> fill(rowptr, rowptr + m);
-    for (size_t q = 0; q < cnt; q++) {
-        uint32_t k = order[q];
-        colids[fill[rows[k]]++] = cols[k];
+    if (!rowptr) return fail(F2V_ENOMEM, "f2v_read_mtx: out of memory");
+    std::vector<std::atomic<uint32_t>> fill((size_t)m);
+    for (auto &f : fill) f.store(0, std::memory_order_relaxed);
+    auto for_entries = [&](unsigned t, auto &&emit) {
+        const Part &P = parts[t];
+        const uint64_t lim = nz > line0[t] ? std::min<uint64_t>(nz - line0[t], P.r.size()) : 0;
+        for (uint64_t k = 0; k < lim; k++) {
+            const uint32_t r = P.r[k], c = P.c[k];
+            if (r == kSkip) continue;
+            if (symmetric) {
+                if (r == c) continue;  // IO.h:131-134: diagonal entries of a symmetric file are dropped
+                emit(r, c);
+                emit(c, r);
+            } else {
+                emit(r, c);
+            }
+        }
+    };
+    run_parallel(T, [&](unsigned t) { for_entries(t, [&](uint32_t r, uint32_t) { fill[r].fetch_add(1, std::memory_order_relaxed); }); });
+    uint64_t cnt = 0;
+    for (size_t i = 0; i < m; i++) {
+        rowptr[i] = (uint32_t)cnt;
+        cnt += fill[i].load(std::memory_order_relaxed);
+        if (cnt >= 0xFFFFFFFFull) { free(rowptr); return fail(F2V_EINVAL, "f2v_read_mtx: nnz exceeds 32-bit row pointers"); }
+        fill[i].store(rowptr[i], std::memory_order_relaxed);
     }
+    rowptr[m] = (uint32_t)cnt;
+    lap("count rows");
+    uint32_t *colids = (uint32_t *)malloc((cnt ? cnt : 1) * sizeof(uint32_t));
+    if (!colids) { free(rowptr); return fail(F2V_ENOMEM, "f2v_read_mtx: out of memory"); }
+    run_parallel(T, [&](unsigned t) { for_entries(t, [&](uint32_t r, uint32_t c) { colids[fill[r].fetch_add(1, std::memory_order_relaxed)] = c; }); });
+    lap("scatter");
+    // ascending column ids inside each row (duplicates kept): CSC sort + transpose of the reference (CSC.h:173-186, CSR.h:172-182)
+    std::atomic<uint64_t> next_row{0};
+    run_parallel(T, [&](unsigned) {
+        for (;;) {
+            const uint64_t i0 = next_row.fetch_add(4096, std::memory_order_relaxed);
+            if (i0 >= m) break;
+            const uint64_t i1 = std::min<uint64_t>(i0 + 4096, m);
+            for (uint64_t i = i0; i < i1; i++) std::sort(colids + rowptr[i], colids + rowptr[i + 1]);
+        }
+    });
+    lap("sort rows");
     *n_out = (uint32_t)m;
     *nnz_out = cnt;
     *rowptr_out = rowptr;
