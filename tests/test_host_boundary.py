@@ -155,3 +155,17 @@ def test_binary_csr_cache_and_binary_embd(tmp_path):
     F.write_embd_bin(tmp_path / "x.bin", X)
     D = np.fromfile(tmp_path / "x.bin", np.float32)  # readBinEmbeddings, runnodeclassclust.py:81-86
     assert np.array_equal(D.reshape(-1, 16), X)
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/f2v.h is a C header (no C++ or torch types in the signatures) and a C program links against libf2v."""
+    src = tmp_path / "t.c"
+    src.write_text('#include "f2v.h"\n#include <stdio.h>\nint main(void){ f2v_rng *g = f2v_rng_create(1); int v = f2v_rng_next(g); f2v_rng_destroy(g);'
+                   ' printf("%d %s\\n", v, f2v_version()); f2v_handle h = 0; unsigned rp[3] = {0,0,0};'
+                   ' int rc = f2v_create(rp, 0, 2, 0, 8, 0, &h); if (rc == 0) f2v_destroy(h); else printf("%s\\n", f2v_last_error()); return 0; }\n')
+    exe = tmp_path / "t"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-lf2v", "-Wl,-rpath," + libdir])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("1804289383 f2v-mi355x"), out.stdout + out.stderr
