@@ -320,6 +320,53 @@ def test_cli_binary_cache_and_output(F, tmp_path):
     assert np.array_equal(X, want)
 
 
+def test_rmat20_full_size_properties(F):
+    """BASELINE configs[2] at full size (RMAT scale-20: 1 048 576 vertices, 31.4 M nonzeros, D = 128): two
+    engines run one epoch of f2v_train (batch 65536) -> identical bits (determinism); then one more minibatch
+    is checked on sampled rows -- zero-degree rows and the batch's largest hubs included -- against the
+    oracle's row function on the downloaded pre-step matrix, rows outside the batch must not change, and a
+    zero-degree row's update must equal the closed form of its five repulsive sample forces alone."""
+    from force2vec_amd.graph import rmat_csr
+    rowptr, colids = rmat_csr(20, 16, seed=1)
+    n, dim, batch = len(rowptr) - 1, 128, 65536
+    deg = np.diff(rowptr.astype(np.int64))
+    engs = []
+    for _ in range(2):
+        e = F.Engine(rowptr, colids, dim)
+        e.srand(1)
+        e.init_embeddings(0)
+        e.train(5, 1, batch)
+        engs.append(e)
+    before = engs[0].get_embeddings()
+    assert np.array_equal(before, engs[1].get_embeddings())
+    engs[1].close()
+    eng = engs[0]
+    chunk = eng.get_param("hub_chunk")
+    rng = np.random.default_rng(9)
+    lo, hi = 5 * batch, 6 * batch
+    ids = rng.integers(0, n - 1, 5).astype(np.uint32)
+    eng.minibatch_step(5, lo, hi, ids, 5, 0.02)
+    after = eng.get_embeddings()
+    zero_rows = lo + np.flatnonzero(deg[lo:hi] == 0)[:8]
+    rows = np.concatenate([rng.integers(lo, hi, 32), lo + np.argsort(deg[lo:hi])[-4:], zero_rows])
+    assert deg[rows].max() > 8 * chunk and len(zero_rows) == 8
+    for i in rows:
+        want = O.row(5, rowptr, colids, before, int(i), ids, 0.02, order=O.ORDER_TREE, chunk=chunk)
+        assert np.array_equal(after[i], want), (i, deg[i])
+    outside = np.ones(n, bool)
+    outside[lo:hi] = False
+    assert np.array_equal(after[outside], before[outside])
+    for i in zero_rows:  # closed form: only the ns repulsive terms, clamp(diff * 2/(r(1+r))) * lr each
+        y = np.zeros(dim, np.float32)
+        for sid in ids:
+            diff = before[i] - before[sid]
+            r = float(tree_sum_model((diff * diff)[None, :])[0])
+            d1 = np.float32(2.0 / (r * (1.0 + r)))
+            y = (y + np.float32(0.02) * np.clip(diff * d1, -5, 5).astype(np.float32)).astype(np.float32)
+        assert np.array_equal(after[i], (before[i] + y).astype(np.float32))
+    eng.close()
+
+
 def test_full_size_sampled_rows(F):
     """RMAT scale-16 (65 536 vertices, ~1 M nnz, hubs of thousands of neighbours) at D = 128: one
     epoch in 4 minibatches, checked on sampled rows (hubs included) against the oracle's row
