@@ -56,6 +56,10 @@ CASES = [
     ("cora.mtx", 7, 300, 256, 128, 0, False),
     ("citeseer.mtx", 5, 5, 500, 32, 0, False),
     ("citeseer.mtx", 6, 5, 500, 32, 0, False),
+    ("pubmed.mtx", 5, 3, 384, 128, 0, False),      # 19 717 vertices, 88 648 nonzeros, max degree 171
+    ("pubmed.mtx", 6, 3, 2048, 64, 0, False),
+    ("pubmed.mtx", 7, 2, 1000, 128, 0, False),
+    ("cora.mtx", 5, 3, 256, 256, 0, False),        # D = 256
 ]
 
 
@@ -88,7 +92,7 @@ def main():
     for g in ("karate.mtx", "cora.mtx"):
         shutil.copy(os.path.join(REF_INPUT, g), os.path.join(GOLD, g))
     shutil.copy(os.path.join(REF_INPUT, "cora.nodes.labels"), os.path.join(GOLD, "cora.nodes.labels"))
-    for g in ("citeseer.mtx",):
+    for g in ("citeseer.mtx", "pubmed.mtx"):
         with open(os.path.join(REF_INPUT, g), "rb") as fi, gzip.GzipFile(os.path.join(GOLD, g + ".gz"), "wb", mtime=0) as fo:
             fo.write(fi.read())
     t, ok = O.sm_table_as_compiled()

@@ -220,7 +220,9 @@ TRAIN_CASES = [("karate.mtx", 5, 10, 16, 16, 0), ("karate.mtx", 5, 10, 7, 16, 1)
                ("karate.mtx", 6, 10, 16, 16, 0), ("karate.mtx", 6, 10, 7, 32, 1), ("karate.mtx", 7, 10, 16, 16, 0),
                ("karate.mtx", 7, 5, 5, 128, 0), ("cora.mtx", 5, 10, 256, 16, 0), ("cora.mtx", 5, 10, 256, 128, 0),
                ("cora.mtx", 5, 10, 384, 128, 0), ("cora.mtx", 5, 5, 256, 64, 1), ("cora.mtx", 6, 10, 256, 128, 0),
-               ("cora.mtx", 6, 5, 256, 64, 1), ("cora.mtx", 7, 10, 256, 128, 0), ("citeseer.mtx", 5, 5, 500, 32, 0)]
+               ("cora.mtx", 6, 5, 256, 64, 1), ("cora.mtx", 7, 10, 256, 128, 0), ("citeseer.mtx", 5, 5, 500, 32, 0),
+               ("pubmed.mtx", 5, 3, 384, 128, 0), ("pubmed.mtx", 6, 3, 2048, 64, 0), ("pubmed.mtx", 7, 2, 1000, 128, 0),
+               ("cora.mtx", 5, 3, 256, 256, 0)]
 
 
 @pytest.mark.parametrize("graph,option,iters,batch,dim,bs", TRAIN_CASES)
@@ -243,6 +245,11 @@ def test_train_bit_exact_vs_oracle_and_close_to_reference(F, graph, option, iter
         ref = O.read_embd(tmp)
         # golden text has 6 significant digits: 5e-6 print resolution for |x| < 10, plus the fp32 order tolerance
         assert np.abs(algo.nCoordinates - ref).max() < 3e-5
+    elif iters <= 5:
+        # no reference text committed for this case (its md5 is, and the CPU suite checks the oracle against it):
+        # compare with the oracle in the reference's own summation order
+        ref = O.train(option, rowptr, colids, dim, iters, batch, bs_mode=bs, order=O.ORDER_REF)
+        assert np.abs(algo.nCoordinates - ref).max() < 1e-5
     algo.engine.close()
 
 
