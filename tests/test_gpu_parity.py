@@ -476,3 +476,21 @@ def test_fast_rng_mode_is_statistically_equivalent(F, manifest):
         assert abs(mic - ref["%.2f" % tf]["micro"]) <= 1.5, (tf, mic)
     for tf in scores[(7, 0)]:                                         # option 7: device walks vs the reference's walks
         assert abs(scores[(7, 1)][tf][0] - scores[(7, 0)][tf][0]) <= 2.5, (tf, scores[(7, 1)][tf], scores[(7, 0)][tf])
+
+
+def test_cora_link_prediction_matches_reference(F):
+    """sForce2Vec (option 6, the variant the reference's README recommends for link prediction): 300 epochs on
+    Cora on the GPU, scored with the seeded restatement of performancescores/runlinkpredict.py on the same pair
+    set and split as the reference-order embedding: accuracy / F1 within half a point."""
+    import linkpred_harness as L
+    rowptr, colids = F.read_mtx(golden_graph_path("cora.mtx"))
+    pairs = L.pair_set(rowptr, colids, seed=0)
+    algo = F.algorithms((rowptr, colids), dim=128)
+    algo.srand(1)
+    algo._run(6, 0, 300, 256, 5, 0.02, write=False)
+    got = L.link_scores(algo.nCoordinates, pairs)
+    ref = L.link_scores(O.train(6, rowptr, colids, 128, 300, 256, order=O.ORDER_REF), pairs)
+    assert ref[0] > 95.0
+    for g, r in zip(got, ref):
+        assert abs(g - r) <= 0.5, (got, ref)
+    algo.engine.close()
