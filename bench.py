@@ -131,6 +131,8 @@ def main():
     ap.add_argument("--cpu-scale", type=int, default=17)
     ap.add_argument("--cpu-iters", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", choices=["allgather", "need"], default="allgather",
+                    help="N>1: all-gather of every minibatch's new rows, or per-destination sends of only the rows each rank reads")
     ap.add_argument("--force-dist", action="store_true", help="drive even a single rank through the multi-GPU path (RCCL group of 1): self-test")
     ap.add_argument("--extra-batches", type=str, default="256,4096,16384", help="comma list of further batch sizes to time (reported under 'extra')")
     args = ap.parse_args()
@@ -184,7 +186,8 @@ def main():
             eng.train(args.option, k, batch, 5, 0.02, 0)
             return eng.stats()
         s0 = eng.stats()
-        comm = fdist.NcclStageComm(dist, rank, world, local_rank)
+        comm = (fdist.NeedExchange(dist, rank, world, device=local_rank, backend="device") if args.exchange == "need"
+                else fdist.NcclStageComm(dist, rank, world, local_rank))
         fdist.ShardedTrainer(eng, rank, world, comm, exchange_when_single=True).train(args.option, k, batch, 5, 0.02, 0)
         s1 = eng.stats()
         st = {key: s1[key] - s0[key] for key in s1}
@@ -215,7 +218,7 @@ def main():
         "config": {"workload": "RMAT scale-%d edge-factor 16 (n=%d, nnz=%d directed CSR nonzeros), option %d, D=%d, ns=5, lr=0.02, batch=%d; step = 1 epoch"
                    % (args.scale, n, nnz, args.option, args.dim, args.batch),
                    "batch": args.batch, "hub_chunk": eng.get_param("hub_chunk"),
-                   "parallelism": "1 GPU" if world == 1 else "minibatch rows sharded over %d GPUs, replicated graph+matrix, RCCL all-gather of staged rows" % world},
+                   "parallelism": "1 GPU" if world == 1 else "minibatch rows sharded over %d GPUs, replicated graph+matrix, RCCL %s of the new rows" % (world, "all-gather" if args.exchange == "allgather" else "all-to-all-v (per-destination)")},
     }
     if st is not None:
         # dominant kernel = qstep_kernel, one launch per minibatch; launch time from HIP events on the

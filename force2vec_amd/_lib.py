@@ -45,6 +45,8 @@ SIGNATURES = {
     "f2v_stage_read": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, f32p]),
     "f2v_stage_write": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, f32p]),
     "f2v_stage_reserve": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "f2v_rows_read": (C.c_int, [C.c_void_p, u32p, C.c_uint32, f32p]),
+    "f2v_rows_write": (C.c_int, [C.c_void_p, u32p, C.c_uint32, f32p]),
     "f2v_embeddings_device_ptr": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "f2v_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "f2v_synchronize": (C.c_int, [C.c_void_p]),

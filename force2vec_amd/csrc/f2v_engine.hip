@@ -744,6 +744,30 @@ int f2v_stage_write(f2v_handle c, uint32_t row_lo, uint32_t row_hi, const float 
     return F2V_OK;
 }
 
+int f2v_rows_read(f2v_handle c, const uint32_t *ids, uint32_t count, float *out) {
+    if (!c || (count && (!ids || !out))) return fail(F2V_EINVAL, "f2v_rows_read: null argument");
+    HIPC(hipSetDevice(c->device));
+    HIPC(hipStreamSynchronize(c->stream));
+    const float *base = c->d_X[c->cur ^ 1];
+    for (uint32_t k = 0; k < count; k++) {
+        if (ids[k] >= c->n) return fail(F2V_EINVAL, "f2v_rows_read: id %u is not a vertex", ids[k]);
+        HIPC(hipMemcpy(out + (size_t)k * c->D, base + (size_t)ids[k] * c->D, (size_t)c->D * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return F2V_OK;
+}
+
+int f2v_rows_write(f2v_handle c, const uint32_t *ids, uint32_t count, const float *in) {
+    if (!c || (count && (!ids || !in))) return fail(F2V_EINVAL, "f2v_rows_write: null argument");
+    HIPC(hipSetDevice(c->device));
+    HIPC(hipStreamSynchronize(c->stream));
+    float *base = c->d_X[c->cur ^ 1];
+    for (uint32_t k = 0; k < count; k++) {
+        if (ids[k] >= c->n) return fail(F2V_EINVAL, "f2v_rows_write: id %u is not a vertex", ids[k]);
+        HIPC(hipMemcpy(base + (size_t)ids[k] * c->D, in + (size_t)k * c->D, (size_t)c->D * sizeof(float), hipMemcpyHostToDevice));
+    }
+    return F2V_OK;
+}
+
 int f2v_embeddings_device_ptr(f2v_handle c, uint64_t *out) {
     if (!c || !out) return fail(F2V_EINVAL, "null argument");
     *out = (uint64_t)(uintptr_t)c->d_X[c->cur];  // the whole matrix only after f2v_flush

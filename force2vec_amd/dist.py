@@ -87,12 +87,163 @@ class NcclStageComm:
             self.dist.all_gather_into_tensor(full, mine)
 
 
+def row_owner(n, batch, world):
+    """(batch index, owning rank) of every row under shard_bounds' contiguous equal slices."""
+    rows = np.arange(n, dtype=np.int64)
+    b = rows // batch
+    lo = b * batch
+    per = -(-(np.minimum(lo + batch, n) - lo) // world)
+    return b, (rows - lo) // per
+
+
+class NeedExchange:
+    """Per-destination exchange: a rank receives only the rows it reads.
+
+    Which rows those are is static: the CSR neighbours of the rows the rank computes, plus every vertex the
+    run's (pre-drawn) sample ids name.  After each minibatch a rank packs, for every other rank, the rows of
+    its slice that rank needs, and one all-to-all-v moves them; rows nobody else reads never travel (on RMAT-20
+    that is 0.52 / 0.43 / 0.34 of the all-gather volume at 2 / 4 / 8 ranks).  Replicas are then complete only
+    in the rows their rank reads, so `finish` all-gathers the final matrix once.  Options 5/6 only (option 7's
+    neighbours are the epoch's walks).  Results are bit-identical to the all-gather exchange.
+
+    backend "device": pack/unpack are index_select / index_copy_ on a zero-copy torch view of the engine's
+    matrices, the collective is RCCL's all_to_all_single on the engine's stream; backend "host": rows travel
+    through f2v_rows_read / f2v_rows_write and CPU tensors (gloo) -- tests.
+    """
+
+    def __init__(self, dist, rank, world, device=None, backend="device"):
+        self.dist, self.rank, self.world, self.device, self.backend = dist, rank, world, device, backend
+        if backend == "device":
+            import torch
+            self.torch = torch
+            self._views = {}
+            self._stream = None
+            # a process group that cannot move device tensors (gloo) still exercises the device-side pack / unpack:
+            # the collectives then go through host copies (two ranks sharing the one GPU of a test box)
+            self.bounce = dist.get_backend() != "nccl"
+        self.plan_key = None
+
+    # -- setup -----------------------------------------------------------------------------------------
+    def prepare(self, engine, batch, sample_ids):
+        import torch
+        n, w = engine.n, self.world
+        key = (n, batch, w, hash(np.asarray(sample_ids).tobytes()))
+        if self.backend == "device" and self._stream is None:
+            self._stream = torch.cuda.ExternalStream(engine.stream(), device=self.device)
+        if key == self.plan_key:
+            return
+        self.batch = batch
+        self.nb = -(-n // batch)
+        b_of, owner = row_owner(n, batch, w)
+        self.owner = owner
+        deg = np.diff(engine.rowptr.astype(np.int64))
+        mine_edges = np.repeat(owner == self.rank, deg)
+        need = np.union1d(np.unique(engine.colids[mine_edges]).astype(np.int64), np.unique(np.asarray(sample_ids, dtype=np.int64)))
+        need = need[owner[need] != self.rank]
+        order = np.lexsort((need, b_of[need], owner[need]))        # by source rank, then batch, then row
+        need = need[order]
+        recv_cnt = np.zeros((self.nb, w), dtype=np.int64)
+        np.add.at(recv_cnt, (b_of[need], owner[need]), 1)
+        # tell every source which of its rows this rank needs (counts per batch, then the ids)
+        dev = torch.device("cuda", self.device) if (self.backend == "device" and not self.bounce) else torch.device("cpu")
+        cnt_in = torch.from_numpy(np.ascontiguousarray(recv_cnt.T).reshape(-1)).to(dev)
+        cnt_out = torch.empty_like(cnt_in)
+        self.dist.all_to_all_single(cnt_out, cnt_in)
+        send_cnt = cnt_out.cpu().numpy().reshape(w, self.nb).T.copy()             # [batch, destination]
+        ids_in = torch.from_numpy(need).to(dev)
+        ids_out = torch.empty(int(send_cnt.sum()), dtype=torch.int64, device=dev)
+        self.dist.all_to_all_single(ids_out, ids_in, output_split_sizes=send_cnt.sum(0).tolist(), input_split_sizes=recv_cnt.sum(0).tolist())
+        send_ids = ids_out.cpu().numpy()                                             # by destination, then batch, then row
+        # regroup both lists per batch: batch b sends [dst 0 rows | dst 1 rows | ...], receives [src 0 | src 1 | ...]
+        def per_batch(ids, cnt):
+            out, start = [[] for _ in range(self.nb)], 0
+            for r in range(w):
+                for b in range(self.nb):
+                    out[b].append(ids[start: start + cnt[b, r]])
+                    start += cnt[b, r]
+            return [np.concatenate(x) if x else np.zeros(0, np.int64) for x in out]
+        self.send_ids, self.recv_ids = per_batch(send_ids, send_cnt), per_batch(need, recv_cnt)
+        self.send_cnt, self.recv_cnt = send_cnt, recv_cnt
+        assert all(np.all(owner[x] == self.rank) for x in self.send_ids)
+        if self.backend == "device":
+            gpu = torch.device("cuda", self.device)
+            self.send_idx = [torch.from_numpy(x).to(gpu) for x in self.send_ids]
+            self.recv_idx = [torch.from_numpy(x).to(gpu) for x in self.recv_ids]
+        self.rows_sent_per_epoch = int(send_cnt.sum())
+        self.plan_key = key
+
+    def _matrix2d(self, engine, base_ptr, rows):
+        v = self._views.get(base_ptr)
+        if v is None:
+            v = self.torch.as_tensor(_DevBuf(base_ptr, rows * engine.dim), device=self.torch.device("cuda", self.device)).view(rows, engine.dim)
+            self._views[base_ptr] = v
+        return v
+
+    # -- per minibatch ---------------------------------------------------------------------------------
+    def exchange(self, engine, lo, hi):
+        import torch
+        b = lo // self.batch
+        s_split, r_split = self.send_cnt[b].tolist(), self.recv_cnt[b].tolist()
+        if self.world == 1:
+            return  # a single rank owns and reads everything
+        if self.backend == "device":
+            ptr, cap = engine.stage_device_ptr()
+            xn = self._matrix2d(engine, ptr - lo * engine.dim * 4, cap + lo)
+            with torch.cuda.stream(self._stream):
+                sendbuf = xn.index_select(0, self.send_idx[b])
+                if self.bounce:
+                    host = torch.empty((int(sum(r_split)), engine.dim), dtype=torch.float32)
+                    self.dist.all_to_all_single(host, sendbuf.cpu(), output_split_sizes=r_split, input_split_sizes=s_split)
+                    recvbuf = host.to(xn.device)
+                else:
+                    recvbuf = torch.empty((int(sum(r_split)), engine.dim), dtype=torch.float32, device=xn.device)
+                    self.dist.all_to_all_single(recvbuf, sendbuf, output_split_sizes=r_split, input_split_sizes=s_split)
+                xn.index_copy_(0, self.recv_idx[b], recvbuf)
+        else:
+            sendbuf = torch.from_numpy(engine.rows_read(self.send_ids[b]) if len(self.send_ids[b]) else np.zeros((0, engine.dim), np.float32))
+            recvbuf = torch.empty((int(sum(r_split)), engine.dim), dtype=torch.float32)
+            self.dist.all_to_all_single(recvbuf, sendbuf, output_split_sizes=r_split, input_split_sizes=s_split)
+            if len(self.recv_ids[b]):
+                engine.rows_write(self.recv_ids[b], recvbuf.numpy())
+
+    # -- once, after the last epoch -----------------------------------------------------------------------
+    def finish(self, engine):
+        """Make every replica the complete final matrix (the caller has flushed the engine)."""
+        import torch
+        n, d, w = engine.n, engine.dim, self.world
+        if self.backend == "device":
+            x = self._matrix2d(engine, engine.embeddings_device_ptr(), n + 4096).view(-1)
+            with torch.cuda.stream(self._stream):
+                for b in range(self.nb):
+                    lo, hi = b * self.batch, min((b + 1) * self.batch, n)
+                    per, _, _ = shard_bounds(lo, hi, self.rank, w)
+                    full = x[lo * d: (lo + per * w) * d]
+                    mine = full[self.rank * per * d: (self.rank + 1) * per * d]
+                    if self.bounce:
+                        host = torch.empty(per * w * d, dtype=torch.float32)
+                        self.dist.all_gather_into_tensor(host, mine.cpu())
+                        full.copy_(host.to(x.device))
+                    else:
+                        self.dist.all_gather_into_tensor(full, mine)
+            engine.synchronize()
+            torch.cuda.current_stream().synchronize()
+        else:
+            X = engine.get_embeddings()
+            mine = np.flatnonzero(self.owner == self.rank)
+            parts = [None] * w
+            self.dist.all_gather_object(parts, (mine, X[mine]))
+            for ids, rows in parts:
+                X[ids] = rows
+            engine.set_embeddings(X)
+
+
 class ShardedTrainer:
     """AlgoForce2Vec* over `world` engines: same epochs, minibatches and rand() order as f2v_train."""
 
     def __init__(self, engine, rank, world, comm, exchange_when_single=False):
         self.engine, self.rank, self.world, self.comm = engine, rank, world, comm
         self.exchange_when_single = exchange_when_single  # self-test of the exchange path on one rank
+        self.need_based = isinstance(comm, NeedExchange)
 
     def train(self, option, iters, batch, ns=5, lr=0.02, bs_mode=0):
         e = self.engine
@@ -103,24 +254,38 @@ class ShardedTrainer:
         nb = -(-n // batch)
         if e.get_param("hub_chunk_auto"):
             e.set_param("hub_chunk_for_batch", batch)  # same chunk as the single-GPU f2v_train, whatever the world size
-        self.comm.prepare(e, min(batch, n))
+        if self.need_based and math == 7:
+            raise ValueError("the per-destination exchange needs static neighbour lists: options 5/6 only")
         ndraw = ns * batch if bs_mode else ns
         stride = (min(batch, n) + ns) if bs_mode else ns
-        for _ in range(iters):
-            if math == 7:
-                e.generate_walks()  # same stream on every rank: sample/algorithms.cpp:1097-1118
-            # the epoch's sample ids do not depend on the embeddings: draw them now (option 7 draws them after
-            # the walks, as the reference's rand() order has it) and keep them in HBM -- no sync per minibatch
+
+        def draw_epoch():
+            # the epoch's sample ids do not depend on the embeddings (option 7 draws them after the walks, as the
+            # reference's rand() order has it); kept in HBM for the whole epoch -- no sync per minibatch
             ids = np.zeros(nb * stride, dtype=np.uint32)
             for b in range(nb):
                 maxv = min((b + 1) * batch, n - 1) if math == 7 else n - 1  # algorithms.cpp:1125
                 keep = min(stride, ndraw)  # -bs 1 draws ns*BATCH ids of which rows+ns-1 are ever read
                 ids[b * stride: b * stride + keep] = e.draw_samples(maxv, ndraw, keep)
-            e.upload_sample_ids(ids)
+            return ids
+
+        all_ids = None
+        if self.need_based:
+            all_ids = [draw_epoch() for _ in range(iters)]  # who samples what decides which rows must travel
+            self.comm.prepare(e, batch, np.concatenate(all_ids) if all_ids else np.zeros(0, np.uint32))
+        else:
+            self.comm.prepare(e, min(batch, n))
+        exchanging = self.world > 1 or self.exchange_when_single
+        for it in range(iters):
+            if math == 7:
+                e.generate_walks()  # same stream on every rank: sample/algorithms.cpp:1097-1118
+            e.upload_sample_ids(all_ids[it] if all_ids is not None else draw_epoch())
             for b in range(nb):
                 lo, hi = b * batch, min((b + 1) * batch, n)
                 _, my_lo, my_hi = shard_bounds(lo, hi, self.rank, self.world)
                 e.minibatch_step_at(option, lo, hi, b * stride, ns, lr, bs_mode, row_lo=my_lo, row_hi=my_hi)
-                if self.world > 1 or self.exchange_when_single:
+                if exchanging:
                     self.comm.exchange(e, lo, hi)
         e.flush()
+        if self.need_based and exchanging:
+            self.comm.finish(e)

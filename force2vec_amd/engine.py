@@ -133,6 +133,23 @@ class Engine:
         assert rows.shape == (row_hi - row_lo, self.dim)
         check(self._L.f2v_stage_write(self._h, row_lo, row_hi, _f32(rows)))
 
+    def rows_read(self, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        out = np.empty((len(ids), self.dim), dtype=np.float32)
+        check(self._L.f2v_rows_read(self._h, _u32(ids), len(ids), _f32(out)))
+        return out
+
+    def rows_write(self, ids, rows):
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        assert rows.shape == (len(ids), self.dim)
+        check(self._L.f2v_rows_write(self._h, _u32(ids), len(ids), _f32(rows)))
+
+    def embeddings_device_ptr(self):
+        p = C.c_uint64()
+        check(self._L.f2v_embeddings_device_ptr(self._h, C.byref(p)))
+        return p.value
+
     def stage_device_ptr(self):
         p = C.c_uint64()
         cap = C.c_uint32()

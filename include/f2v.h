@@ -117,6 +117,10 @@ int f2v_stage_device_ptr(f2v_handle h, uint64_t *devptr_out, uint32_t *capacity_
 int f2v_stage_read(f2v_handle h, uint32_t row_lo, uint32_t row_hi, float *out);
 int f2v_stage_write(f2v_handle h, uint32_t row_lo, uint32_t row_hi, const float *in);
 int f2v_stage_reserve(f2v_handle h, uint32_t rows);
+/* Arbitrary rows of the matrix the staged rows live in (the epoch's second matrix), by vertex id: the
+ * per-destination exchange ("send a row only to the ranks that read it") packs and unpacks with these. */
+int f2v_rows_read(f2v_handle h, const uint32_t *ids, uint32_t count, float *out);
+int f2v_rows_write(f2v_handle h, const uint32_t *ids, uint32_t count, const float *in);
 /* Device address of the embedding matrix and the HIP stream (as integers) for zero-copy wrapping. */
 int f2v_embeddings_device_ptr(f2v_handle h, uint64_t *devptr_out);
 int f2v_stream(f2v_handle h, uint64_t *stream_out);

@@ -73,6 +73,22 @@ class OracleEngine:
         lo, hi, rows = self.pending
         rows[row_lo - lo: row_hi - lo] = data
 
+    def rows_read(self, ids):
+        lo, hi, rows = self.pending
+        ids = np.asarray(ids, dtype=np.int64)
+        assert np.all((ids >= lo) & (ids < hi))
+        return rows[ids - lo].copy()
+
+    def rows_write(self, ids, data):
+        lo, hi, rows = self.pending
+        ids = np.asarray(ids, dtype=np.int64)
+        assert np.all((ids >= lo) & (ids < hi))
+        rows[ids - lo] = data
+
+    def set_embeddings(self, X):
+        self.pending = None
+        self.X = np.array(X, dtype=np.float32)
+
     def flush(self):
         self._commit()
 

@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, case, outdir):
+def _worker(rank, world, port, case, outdir, exchange="allgather"):
     import torch.distributed as dist
     from fake_engine import OracleEngine
     from force2vec_amd import dist as fdist
@@ -30,8 +30,11 @@ def _worker(rank, world, port, case, outdir):
     eng = OracleEngine(rp, ci, dim, chunk=4)
     eng.srand(1)
     eng.init_embeddings(0 if option == 5 else 1)
-    fdist.ShardedTrainer(eng, rank, world, fdist.HostStageComm(dist, rank, world)).train(option, iters, batch, 5, 0.02, bs)
+    comm = fdist.HostStageComm(dist, rank, world) if exchange == "allgather" else fdist.NeedExchange(dist, rank, world, backend="host")
+    fdist.ShardedTrainer(eng, rank, world, comm).train(option, iters, batch, 5, 0.02, bs)
     np.save(os.path.join(outdir, "r%d.npy" % rank), eng.get_embeddings())
+    if exchange == "need":
+        np.save(os.path.join(outdir, "sent%d.npy" % rank), np.array([comm.rows_sent_per_epoch]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -51,6 +54,35 @@ def test_sharded_training_equals_single_process(case, world, tmp_path):
     for r in range(world):
         got = np.load(str(tmp_path / ("r%d.npy" % r)))
         assert np.array_equal(got, want), (r, float(np.nanmax(np.abs(got - want))))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("case", [c for c in CASES if c[1] != 7], ids=["%s-opt%d-B%d-bs%d" % (c[0][:-4], c[1], c[3], c[5]) for c in CASES if c[1] != 7])
+def test_per_destination_exchange_equals_single_process(case, world, tmp_path):
+    """NeedExchange: a rank receives only the rows it reads (CSR neighbours of its rows + every sampled vertex);
+    rows nobody reads stay NaN in the stand-in engine, so a missing row would poison the result."""
+    import torch.multiprocessing as mp
+    graph, option, iters, batch, dim, bs = case
+    mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path), "need"), nprocs=world, join=True)
+    rp, ci = O.read_mtx(golden_graph_path(graph))
+    want = O.train(option, rp, ci, dim, iters, batch, bs_mode=bs, order=O.ORDER_TREE, chunk=4)
+    sent = 0
+    for r in range(world):
+        got = np.load(str(tmp_path / ("r%d.npy" % r)))
+        assert np.array_equal(got, want), (r, int(np.isnan(got).sum()))
+        sent += int(np.load(str(tmp_path / ("sent%d.npy" % r)))[0])
+    assert sent <= (world - 1) * (len(rp) - 1)   # never more than the all-gather moves
+
+
+def test_row_owner_matches_shard_bounds():
+    from force2vec_amd.dist import row_owner, shard_bounds
+    for n, batch, world in ((34, 16, 2), (34, 7, 3), (100, 100, 8), (2708, 256, 3), (9, 4, 4)):
+        b, owner = row_owner(n, batch, world)
+        for lo in range(0, n, batch):
+            hi = min(lo + batch, n)
+            for r in range(world):
+                _, a, e = shard_bounds(lo, hi, r, world)
+                assert np.all(owner[a:e] == r) and np.all(b[a:e] == lo // batch)
 
 
 def test_shard_bounds_cover_the_batch():

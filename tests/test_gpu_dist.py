@@ -33,7 +33,7 @@ def _single(case):
     return X
 
 
-def _gloo_worker(rank, world, port, case, outdir):
+def _gloo_worker(rank, world, port, case, outdir, exchange="allgather"):
     import torch.distributed as dist
     import force2vec_amd as F
     from force2vec_amd import dist as fdist
@@ -43,11 +43,31 @@ def _gloo_worker(rank, world, port, case, outdir):
     eng = F.Engine(rp, ci, dim, device=0)
     eng.srand(1)
     eng.init_embeddings(0 if option in (5, 8, 11) else 1)
-    fdist.ShardedTrainer(eng, rank, world, fdist.HostStageComm(dist, rank, world)).train(option, iters, batch, 5, 0.02, bs)
+    if exchange == "allgather":
+        comm = fdist.HostStageComm(dist, rank, world)
+    elif exchange == "need":
+        comm = fdist.NeedExchange(dist, rank, world, backend="host")
+    else:  # device-side pack / unpack on the engine's stream, collectives bounced through the host (gloo)
+        import torch
+        torch.cuda.set_device(0)
+        comm = fdist.NeedExchange(dist, rank, world, device=0, backend="device")
+    fdist.ShardedTrainer(eng, rank, world, comm).train(option, iters, batch, 5, 0.02, bs)
     np.save(os.path.join(outdir, "r%d.npy" % rank), eng.get_embeddings())
     eng.close()
     dist.barrier()
     dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["need", "need_device"])
+@pytest.mark.parametrize("case", [("cora.mtx", 5, 3, 256, 128, 0), ("cora.mtx", 6, 2, 300, 64, 1)])
+def test_two_gloo_ranks_per_destination_exchange(case, mode, tmp_path):
+    """The same with NeedExchange: rows travel only to the ranks that read them, replicas are completed at the end.
+    "need_device" packs / unpacks with torch ops on zero-copy views of the engine's matrices, on its stream."""
+    import torch.multiprocessing as mp
+    mp.spawn(_gloo_worker, args=(2, _free_port(), case, str(tmp_path), mode), nprocs=2, join=True)
+    want = _single(case)
+    for r in range(2):
+        assert np.array_equal(np.load(str(tmp_path / ("r%d.npy" % r))), want)
 
 
 @pytest.mark.parametrize("case", [("cora.mtx", 5, 3, 256, 128, 0), ("cora.mtx", 6, 2, 384, 128, 0), ("karate.mtx", 7, 3, 16, 64, 0),
@@ -60,7 +80,7 @@ def test_two_gloo_ranks_share_the_gpu(case, tmp_path):
         assert np.array_equal(np.load(str(tmp_path / ("r%d.npy" % r))), want)
 
 
-def _nccl_worker(rank, world, port, case, outdir):
+def _nccl_worker(rank, world, port, case, outdir, exchange="allgather"):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
@@ -73,7 +93,7 @@ def _nccl_worker(rank, world, port, case, outdir):
     eng = F.Engine(rp, ci, dim, device=0)
     eng.srand(1)
     eng.init_embeddings(0)
-    comm = fdist.NcclStageComm(dist, rank, world, 0)
+    comm = fdist.NcclStageComm(dist, rank, world, 0) if exchange == "allgather" else fdist.NeedExchange(dist, rank, world, device=0, backend="device")
     fdist.ShardedTrainer(eng, rank, world, comm, exchange_when_single=True).train(option, iters, batch, 5, 0.02, bs)
     np.save(os.path.join(outdir, "r%d.npy" % rank), eng.get_embeddings())
     eng.close()
@@ -81,8 +101,11 @@ def _nccl_worker(rank, world, port, case, outdir):
     dist.destroy_process_group()
 
 
-def test_rccl_in_place_all_gather_on_engine_stream(tmp_path):
+@pytest.mark.parametrize("exchange", ["allgather", "need"])
+def test_rccl_in_place_all_gather_on_engine_stream(exchange, tmp_path):
+    """Single-rank RCCL group: the zero-copy views, the engine's stream as torch ExternalStream, the in-place
+    all-gather (per minibatch for "allgather", the final completion pass for "need")."""
     import torch.multiprocessing as mp
     case = ("cora.mtx", 5, 3, 256, 128, 0)
-    mp.spawn(_nccl_worker, args=(1, _free_port(), case, str(tmp_path)), nprocs=1, join=True)
+    mp.spawn(_nccl_worker, args=(1, _free_port(), case, str(tmp_path), exchange), nprocs=1, join=True)
     assert np.array_equal(np.load(str(tmp_path / "r0.npy")), _single(case))
