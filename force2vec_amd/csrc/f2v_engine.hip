@@ -535,6 +535,8 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
         if (rc != F2V_OK) return rc;
         HIPC(hipStreamSynchronize(c->stream));
         if (value > (int64_t)kItemSlotMask) return fail(F2V_EINVAL, "hub_chunk out of range");
+        // partial-sum slots are 28-bit: pieces plus the nodes of their combine trees must stay below 2^28
+        if (value > 0 && c->nnz / (uint64_t)value >= (1ull << 27)) return fail(F2V_EINVAL, "hub_chunk %lld is too small for %llu nonzeros", (long long)value, (unsigned long long)c->nnz);
         c->chunk = (uint32_t)value;
         c->chunk_auto = false;
         drop_plans(c);
