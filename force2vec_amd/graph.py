@@ -50,10 +50,7 @@ def csr_from_undirected_edges(n, src, dst):
     rows = (key // n).astype(np.int64)
     colids = (key % n).astype(np.uint32)
     rowptr = np.zeros(n + 1, dtype=np.int64)
-    np.add.at(rowptr, rows + 1, 1) if len(rows) < 1 << 16 else None
-    if len(rows) >= 1 << 16:
-        rowptr[1:] = np.bincount(rows, minlength=n)
-    rowptr = np.cumsum(rowptr)
+    rowptr[1:] = np.cumsum(np.bincount(rows, minlength=n))
     assert rowptr[-1] == len(colids) and rowptr[-1] < 2**32
     return rowptr.astype(np.uint32), colids
 
