@@ -78,6 +78,7 @@ struct f2v_ctx {
     bool fast_rng = false;        // non-parity mode: device-side init and option-7 walks (counter-based RNG)
     uint64_t fast_seed = 1, fast_epoch = 0;
     int rows_in_flight = 4;
+    bool use_graph = false;  // f2v_train replays one hipGraph per epoch parity instead of launching eagerly
     f2v_stats stats{};
 };
 
@@ -571,6 +572,10 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
         c->fast_rng = value != 0;
         return F2V_OK;
     }
+    if (!strcmp(name, "use_graph")) {
+        c->use_graph = value != 0;
+        return F2V_OK;
+    }
     if (!strcmp(name, "rows_in_flight")) {
         if (value != 4 && value != 8) return fail(F2V_EINVAL, "rows_in_flight must be 4 or 8");
         c->rows_in_flight = (int)value;
@@ -591,6 +596,7 @@ int f2v_get_param(f2v_handle c, const char *name, int64_t *out) {
     if (!strcmp(name, "quarter_wave")) { *out = c->use_quarter ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "hub_fanin")) { *out = c->fanin; return F2V_OK; }
     if (!strcmp(name, "fast_rng")) { *out = c->fast_rng ? 1 : 0; return F2V_OK; }
+    if (!strcmp(name, "use_graph")) { *out = c->use_graph ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "hub_chunk_auto")) { *out = c->chunk_auto ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "dim")) { *out = c->D; return F2V_OK; }
     if (!strcmp(name, "n")) { *out = c->n; return F2V_OK; }
@@ -849,7 +855,43 @@ int f2v_train(f2v_handle c, int option, uint32_t iters, uint32_t batch, uint32_t
     HIPC(hipEventCreate(&ev1));
     HIPC(hipEventRecord(ev0, c->stream));
     std::vector<uint32_t> walks;
-    for (uint32_t it = 0; it < iters; it++) {
+    const bool graphed = c->use_graph && math != 7 && all_upfront && iters >= 2;
+    if (graphed) {
+        // hipGraph replay: an epoch's launch chain is identical every epoch except for (a) which of the two matrices
+        // is read and which written -- they alternate, hence one graph per epoch parity -- and (b) the sample ids,
+        // which each replay finds at a fixed place (its parity's region of d_ids), refreshed by a stream-ordered copy.
+        hipGraph_t graph[2] = {nullptr, nullptr};
+        hipGraphExec_t exec[2] = {nullptr, nullptr};
+        for (int par = 0; par < 2; par++) {
+            HIPC(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            for (uint32_t b = 0; b < nb && rc == F2V_OK; b++) {
+                const uint32_t lo = b * batch;
+                const uint32_t hi = (uint32_t)std::min<uint64_t>((uint64_t)lo + batch, n);
+                rc = launch_step(c, math, lo, hi, lo, hi, c->d_ids + (size_t)par * per_epoch + (size_t)b * stride, ns, lr, bs_mode);
+            }
+            hipError_t e = hipStreamEndCapture(c->stream, &graph[par]);
+            if (rc != F2V_OK) return rc;
+            HIPC(e);
+            HIPC(hipGraphInstantiate(&exec[par], graph[par], nullptr, nullptr, 0));
+        }
+        // the host-side bookkeeping now stands where two executed epochs leave it; one epoch's statistics were counted twice
+        f2v_stats one = c->stats;
+        one.step_launches /= 2; one.rows /= 2; one.nnz /= 2; one.algorithmic_bytes /= 2; one.hub_rows /= 2; one.hub_chunks /= 2;
+        HIPC(hipEventRecord(ev0, c->stream));
+        for (uint32_t it = 0; it < iters; it++) {
+            if (it >= 2)
+                HIPC(hipMemcpyAsync(c->d_ids + (size_t)(it & 1) * per_epoch, ids.data() + (size_t)it * per_epoch, per_epoch * sizeof(uint32_t),
+                                    hipMemcpyHostToDevice, c->stream));
+            HIPC(hipGraphLaunch(exec[it & 1], c->stream));
+        }
+        if (iters & 1) c->cur ^= 1;  // an odd number of epochs ends on the other matrix than the two captured ones did
+        c->stats = one;
+        c->stats.step_launches *= iters; c->stats.rows *= iters; c->stats.nnz *= iters; c->stats.algorithmic_bytes *= iters;
+        c->stats.hub_rows *= iters; c->stats.hub_chunks *= iters;
+        HIPC(hipStreamSynchronize(c->stream));
+        for (int par = 0; par < 2; par++) { (void)hipGraphExecDestroy(exec[par]); (void)hipGraphDestroy(graph[par]); }
+    }
+    for (uint32_t it = 0; it < iters && !graphed; it++) {
         if (math == 7 && c->fast_rng) {
             if ((rc = fast_walks(c)) != F2V_OK) return rc;  // stream-ordered: no host work, no synchronisation
         } else if (math == 7) {

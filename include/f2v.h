@@ -59,7 +59,8 @@ int f2v_get_embeddings(f2v_handle h, float *x_out);
  * reference's summation order for every row; unset = chosen from the batch size by f2v_train, or
  * by setting "hub_chunk_for_batch" = B); "hub_fanin": fan-in of the tree that adds a split row's
  * partial sums (0 = one sequential pass); "quarter_wave": 0 selects the one-item-per-wavefront
- * kernel for every D; "waves_per_block"; "rows_in_flight" (4|8).
+ * kernel for every D; "waves_per_block"; "rows_in_flight" (4|8); "use_graph" = 1 makes f2v_train replay a
+ * captured hipGraph per epoch instead of launching eagerly (same results; measured no faster).
  * "fast_rng" = 1 selects the NON-PARITY fast mode: initial embeddings and the option-7
  * walks are generated on the device by a counter-based RNG (same distributions, different numbers than
  * the reference's libc rand() stream); negative-sample ids still come from the handle's rand() stream.

@@ -272,6 +272,27 @@ def test_quarter_wave_and_generic_layouts_agree(F, option, dim):
     assert np.array_equal(res[0], want)
 
 
+@pytest.mark.parametrize("iters", [2, 5, 8])
+@pytest.mark.parametrize("option,batch", [(5, 256), (6, 1000), (5, 5000)])
+def test_hipgraph_replay_equals_eager_launches(F, option, batch, iters):
+    """f2v_train with "use_graph": one captured hipGraph per epoch parity (the two matrices alternate), sample ids
+    refreshed by stream-ordered copies -- identical bits to the eager launch chain, for odd and even epoch counts,
+    and again when training continues on the same handle."""
+    rowptr, colids = F.read_mtx(golden_graph_path("cora.mtx"))
+    res = []
+    for g in (0, 1):
+        e = F.Engine(rowptr, colids, 128)
+        e.set_param("use_graph", g)
+        e.srand(1)
+        e.init_embeddings(0 if option == 5 else 1)
+        e.train(option, iters, batch)
+        a = e.get_embeddings()
+        e.train(option, 3, batch)
+        res.append((a, e.get_embeddings()))
+        e.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
 def test_options_8_to_11_alias_the_same_maths(F):
     rowptr, colids = F.read_mtx(golden_graph_path("karate.mtx"))
     res = {}
