@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange", choices=["allgather", "need"], default="allgather",
                     help="N>1: all-gather of every minibatch's new rows, or per-destination sends of only the rows each rank reads")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo: self-test of the N>1 plumbing on a one-GPU box (all ranks on device 0, exchange through the host)")
     ap.add_argument("--force-dist", action="store_true", help="drive even a single rank through the multi-GPU path (RCCL group of 1): self-test")
     ap.add_argument("--extra-batches", type=str, default="256,4096,16384", help="comma list of further batch sizes to time (reported under 'extra')")
     args = ap.parse_args()
@@ -159,8 +161,12 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "gloo":
+            local_rank = 0
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     rowptr, colids = load_graph(args.scale, 16, 1)
     n, nnz = len(rowptr) - 1, len(colids)
@@ -176,9 +182,11 @@ def main():
     def barrier():
         eng.synchronize()
         if use_dist:
-            torch.cuda.synchronize()
+            if args.dist_backend == "nccl":
+                torch.cuda.synchronize()
             dist.barrier()
-            torch.cuda.synchronize()
+            if args.dist_backend == "nccl":
+                torch.cuda.synchronize()
 
     def run_epochs(k, batch):
         """-> per-rank statistics of these k epochs (launches, algorithmic bytes, device seconds where known)."""
@@ -186,8 +194,11 @@ def main():
             eng.train(args.option, k, batch, 5, 0.02, 0)
             return eng.stats()
         s0 = eng.stats()
-        comm = (fdist.NeedExchange(dist, rank, world, device=local_rank, backend="device") if args.exchange == "need"
-                else fdist.NcclStageComm(dist, rank, world, local_rank))
+        if args.dist_backend == "gloo":
+            comm = fdist.NeedExchange(dist, rank, world, backend="host") if args.exchange == "need" else fdist.HostStageComm(dist, rank, world)
+        else:
+            comm = (fdist.NeedExchange(dist, rank, world, device=local_rank, backend="device") if args.exchange == "need"
+                    else fdist.NcclStageComm(dist, rank, world, local_rank))
         fdist.ShardedTrainer(eng, rank, world, comm, exchange_when_single=True).train(args.option, k, batch, 5, 0.02, 0)
         s1 = eng.stats()
         st = {key: s1[key] - s0[key] for key in s1}
@@ -203,7 +214,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         if use_dist:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, st
@@ -218,7 +229,7 @@ def main():
         "config": {"workload": "RMAT scale-%d edge-factor 16 (n=%d, nnz=%d directed CSR nonzeros), option %d, D=%d, ns=5, lr=0.02, batch=%d; step = 1 epoch"
                    % (args.scale, n, nnz, args.option, args.dim, args.batch),
                    "batch": args.batch, "hub_chunk": eng.get_param("hub_chunk"),
-                   "parallelism": "1 GPU" if world == 1 else "minibatch rows sharded over %d GPUs, replicated graph+matrix, RCCL %s of the new rows" % (world, "all-gather" if args.exchange == "allgather" else "all-to-all-v (per-destination)")},
+                   "parallelism": "1 GPU" if world == 1 else "minibatch rows sharded over %d GPUs, replicated graph+matrix, %s %s of the new rows" % (world, "RCCL" if args.dist_backend == "nccl" else "gloo (host-bounce self-test)", "all-gather" if args.exchange == "allgather" else "all-to-all-v (per-destination)")},
     }
     if st is not None:
         # dominant kernel = qstep_kernel, one launch per minibatch; launch time from HIP events on the
