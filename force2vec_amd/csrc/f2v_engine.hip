@@ -307,20 +307,29 @@ int launch_step(f2v_ctx *c, int math, uint32_t batch_lo, uint32_t batch_hi, uint
     a.lr = lr;
 
     const uint32_t wpb = (uint32_t)c->waves_per_block;
-    const bool quarter = c->use_quarter && c->exact && (c->D == 64 || c->D == 128 || c->D == 256);
-    const uint32_t per_wave = quarter ? 4u : 1u;
+    // sub-wave layout when D is 16, 32, 64, 128 or 256: 16, 8 or 4 work items per wavefront
+    const bool quarter = c->use_quarter && (c->D == 16 || c->D == 32 || c->D == 64 || c->D == 128 || c->D == 256);
+    const uint32_t per_wave = !quarter ? 1u : (c->D == 16 ? 16u : c->D == 32 ? 8u : 4u);
     const uint32_t waves = (plan.n_items + per_wave - 1) / per_wave;
     const uint32_t blocks = (waves + wpb - 1) / wpb;  // 0 when this rank has no row of the batch
     if (blocks == 0) {
         // nothing to compute here; the range bookkeeping below still advances
     } else if (quarter) {
-        const int nb = (int)(c->D / 64);
-#define F2V_Q(OPT, NB, U) hipLaunchKernelGGL((qstep_kernel<OPT, NB, U>), dim3(blocks), dim3(64 * wpb), 0, c->stream, a)
-        // rows in flight per quarter: 4 (D = 128: 80 VGPRs, 6 waves/SIMD); 8 is selectable at D = 128 and
-        // measured 3-9 % slower on RMAT-20 (116 VGPRs, 4 waves/SIMD); D = 64 has the registers for 8
+#define F2V_Q(OPT, LPI, NB, U) hipLaunchKernelGGL((qstep_kernel<OPT, LPI, NB, U>), dim3(blocks), dim3(64 * wpb), 0, c->stream, a)
+        // rows in flight per item: 4 at D = 128 (80 VGPRs, 6 waves/SIMD; 8 is selectable and measured 3-9 % slower
+        // on RMAT-20: 116 VGPRs, 4 waves/SIMD) and at D = 256; 8 where a row is a single dwordx4 per lane (D <= 64)
         const bool u8 = (c->rows_in_flight == 8);
-        if (math == 5) { if (nb == 1) F2V_Q(5, 1, 8); else if (nb == 2) { if (u8) F2V_Q(5, 2, 8); else F2V_Q(5, 2, 4); } else F2V_Q(5, 4, 4); }
-        else { if (nb == 1) F2V_Q(6, 1, 8); else if (nb == 2) { if (u8) F2V_Q(6, 2, 8); else F2V_Q(6, 2, 4); } else F2V_Q(6, 4, 4); }
+        const int o = (math == 5) ? 5 : 6;
+        switch (c->D) {
+            case 16: if (o == 5) F2V_Q(5, 4, 1, 8); else F2V_Q(6, 4, 1, 8); break;
+            case 32: if (o == 5) F2V_Q(5, 8, 1, 8); else F2V_Q(6, 8, 1, 8); break;
+            case 64: if (o == 5) F2V_Q(5, 16, 1, 8); else F2V_Q(6, 16, 1, 8); break;
+            case 128:
+                if (u8) { if (o == 5) F2V_Q(5, 16, 2, 8); else F2V_Q(6, 16, 2, 8); }
+                else { if (o == 5) F2V_Q(5, 16, 2, 4); else F2V_Q(6, 16, 2, 4); }
+                break;
+            default: if (o == 5) F2V_Q(5, 16, 4, 4); else F2V_Q(6, 16, 4, 4); break;
+        }
 #undef F2V_Q
     } else {
         rc = dispatch_layout(c, [&](auto V, auto E) {

@@ -16,8 +16,8 @@
 //   step_kernel  <OPT,VEC,EXACT>  any D <= 512: one item per wavefront, lane l owns dims
 //                                 [l*VEC, l*VEC+VEC); butterfly = DPP xor 1,2,4,8, ds_swizzle 16,
 //                                 v_readlane 32.
-//   qstep_kernel <OPT,NB>         D = 64*NB (64/128/256): FOUR items per wavefront, one per DPP
-//                                 row; every VALU instruction serves four (row, neighbour) pairs.
+//   qstep_kernel <OPT,LPI,NB,U>   D = 4*LPI*NB in {16, 32, 64, 128, 256}: 64/LPI items per wavefront on LPI
+//                                 lanes of a DPP row each; every VALU instruction serves 64/LPI pairs.
 //
 // Minibatch sequencing (Jacobi inside a batch, Gauss-Seidel across batches,
 // sample/algorithms.cpp:588-639) with ONE launch per batch and no copy: the embedding matrix
@@ -305,24 +305,26 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
     store_row<VEC, EXACT>(out, lane, D, Y);
 }
 
-// ---- quarter-wave layout (D = 64*NB, NB in {1,2,4}) ---------------------------------------------
-// Four work items per wavefront, one per 16-lane DPP row.  Lane t of a quarter owns, in each
-// 64-dim block b, the four contiguous dims [64b + 4t, 64b + 4t + 4): every row is NB coalesced
-// 256-byte (16 lanes x dwordx4) loads, the 64-dim block sums are an in-lane pair tree plus the
-// four DPP row steps (xor 1, 2, 4, 8 -- no LDS crossbar, no SGPR hop), and the blocks are added
-// pairwise: the same canonical adjacent-pair tree as the generic layout, so results are
-// bit-identical.  Every VALU instruction now serves four (row, neighbour) pairs instead of one,
-// which takes the kernel from VALU-bound (14 fp64 + 20 fp32 ops per pair) to gather-bound.
-// Items arrive sorted by length, so the four quarters of a wave run almost equally long.
-__device__ __forceinline__ float row16_allreduce_tree(float v) {
+// ---- sub-wave layout: LPI lanes per item, D = 4*LPI*NB ----------------------------------------------
+// 64/LPI work items per wavefront, each on LPI consecutive lanes of a 16-lane DPP row: LPI = 16 with NB = 1, 2, 4
+// blocks (D = 64, 128, 256: four items per wavefront, the "quarter-wave" layout of the flagship D = 128), LPI = 8
+// (D = 32, eight items) and LPI = 4 (D = 16, sixteen items).  Lane t of an item owns, in each block b of 4*LPI dims,
+// the four contiguous dims [4*LPI*b + 4t, +4): every row is NB coalesced (LPI lanes x dwordx4) loads, a block sum
+// is an in-lane pair tree plus log2(LPI) DPP row steps (xor 1, 2, [4, [8]] -- no LDS crossbar, no SGPR hop), and
+// the blocks are added pairwise: the same canonical adjacent-pair tree as the generic layout, so results are
+// bit-identical.  Every VALU instruction serves 64/LPI (row, neighbour) pairs instead of one, which takes the
+// kernel from VALU-bound (14 fp64 + 20 fp32 ops per pair) to gather-bound.  Items arrive sorted by length, so
+// the items of a wave run almost equally long.
+template <int LPI>
+__device__ __forceinline__ float item_allreduce_tree(float v) {
     v = v + dpp_mov<0xB1>(v);
     v = v + dpp_mov<0x4E>(v);
-    v = v + dpp_mov<0x141>(v);
-    v = v + dpp_mov<0x140>(v);
+    if constexpr (LPI >= 8) v = v + dpp_mov<0x141>(v);
+    if constexpr (LPI >= 16) v = v + dpp_mov<0x140>(v);
     return v;
 }
 
-template <int OPT, int NB, bool NEG>
+template <int OPT, int LPI, int NB, bool NEG>
 __device__ __forceinline__ void pair_update_q(const float (&xi)[NB][4], const float4 (&xj4)[NB], float (&Y)[NB][4],
                                               float lr, double c0, const float *table) {
     float xj[NB][4], bs[NB];
@@ -340,7 +342,7 @@ __device__ __forceinline__ void pair_update_q(const float (&xi)[NB][4], const fl
                 diff[b][v] = xi[b][v] - xj[b][v];
                 t[v] = diff[b][v] * diff[b][v];
             }
-            bs[b] = row16_allreduce_tree((t[0] + t[1]) + (t[2] + t[3]));
+            bs[b] = item_allreduce_tree<LPI>((t[0] + t[1]) + (t[2] + t[3]));
         }
         float a;
         if constexpr (NB == 1) a = bs[0];
@@ -366,7 +368,7 @@ __device__ __forceinline__ void pair_update_q(const float (&xi)[NB][4], const fl
             float t[4];
 #pragma unroll
             for (int v = 0; v < 4; ++v) t[v] = xi[b][v] * xj[b][v];
-            bs[b] = row16_allreduce_tree((t[0] + t[1]) + (t[2] + t[3]));
+            bs[b] = item_allreduce_tree<LPI>((t[0] + t[1]) + (t[2] + t[3]));
         }
         float a;
         if constexpr (NB == 1) a = bs[0];
@@ -392,15 +394,15 @@ __device__ __forceinline__ void pair_update_q(const float (&xi)[NB][4], const fl
     }
 }
 
-template <int NB>
+template <int LPI, int NB>
 __device__ __forceinline__ const float *row_src(const StepArgs &a, uint32_t j) {
-    return ((j - a.upd_lo) < a.upd_rows ? a.Xn : a.X) + (size_t)j * (64u * NB);
+    return ((j - a.upd_lo) < a.upd_rows ? a.Xn : a.X) + (size_t)j * (4u * LPI * NB);
 }
 
-// One quarter's list of row ids; `cnt` is this quarter's length, `maxcnt` the wave's (uniform).
-// U rows per quarter (4U per wave) are in flight before the first interaction is evaluated; the
-// ids of the next group are fetched one group ahead.
-template <int OPT, int NB, bool NEG, int U>
+// One item's list of row ids; `cnt` is this item's length, `maxcnt` the wave's (uniform).
+// U rows per item are in flight before the first interaction is evaluated; the ids of the next group are
+// fetched one group ahead.
+template <int OPT, int LPI, int NB, bool NEG, int U>
 __device__ __forceinline__ void qprocess(const StepArgs &a, const uint32_t *ids, uint32_t cnt, uint32_t maxcnt, uint32_t t,
                                          const float (&xi)[NB][4], float (&Y)[NB][4], double c0) {
     uint32_t j[U];
@@ -411,38 +413,43 @@ __device__ __forceinline__ void qprocess(const StepArgs &a, const uint32_t *ids,
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (g + u < cnt) {
-                const float *src = row_src<NB>(a, j[u]) + t * 4;
+                const float *src = row_src<LPI, NB>(a, j[u]) + t * 4;
 #pragma unroll
-                for (int b = 0; b < NB; ++b) xj[u][b] = *reinterpret_cast<const float4 *>(src + 64 * b);
+                for (int b = 0; b < NB; ++b) xj[u][b] = *reinterpret_cast<const float4 *>(src + 4 * LPI * b);
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) j[u] = (g + U + u < cnt) ? ids[g + U + u] : 0u;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (g + u < cnt) pair_update_q<OPT, NB, NEG>(xi, xj[u], Y, a.lr, c0, a.sm_table);
+            if (g + u < cnt) pair_update_q<OPT, LPI, NB, NEG>(xi, xj[u], Y, a.lr, c0, a.sm_table);
         }
     }
 }
 
-__device__ __forceinline__ uint32_t wave_max_of_quarters(uint32_t v) {
-    const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), a1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
-    const uint32_t a2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), a3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
-    const uint32_t m0 = a0 > a1 ? a0 : a1, m1 = a2 > a3 ? a2 : a3;
-    return m0 > m1 ? m0 : m1;
+// the largest value any item of the wave holds (the value is uniform inside an item): a scalar
+template <int LPI>
+__device__ __forceinline__ uint32_t wave_max_of_items(uint32_t v) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int l = 0; l < 64; l += LPI) {
+        const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+        m = x > m ? x : m;
+    }
+    return m;
 }
 
-template <int OPT, int NB, int U>
+template <int OPT, int LPI, int NB, int U>
 __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
-    constexpr uint32_t D = 64u * NB;
+    constexpr uint32_t D = 4u * LPI * NB, IPW = 64u / LPI;  // dims; items per wavefront
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t t = lane & 15u, q = lane >> 4;
+    const uint32_t t = lane & (LPI - 1u), q = lane / LPI;
     const uint32_t wpb = blockDim.x >> 6;
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + (threadIdx.x >> 6)));
-    if (4u * w >= a.n_items) return;
+    if (IPW * w >= a.n_items) return;
 
-    // this quarter's item (quarters past the end of the list idle with cnt = 0)
-    const uint32_t idx = 4u * w + q;
+    // this item's lanes (lane groups past the end of the list idle with cnt = 0)
+    const uint32_t idx = IPW * w + q;
     const bool active = idx < a.n_items;
     Item it;
     if (active) it = a.items[idx];
@@ -457,7 +464,7 @@ __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
         const float *src = a.X + (size_t)row * D + t * 4;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const float4 v = *reinterpret_cast<const float4 *>(src + 64 * b);
+            const float4 v = *reinterpret_cast<const float4 *>(src + 4 * LPI * b);
             xi[b][0] = v.x; xi[b][1] = v.y; xi[b][2] = v.z; xi[b][3] = v.w;
         }
     }
@@ -477,11 +484,11 @@ __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
         c0 = (double)(a.lr * degi);
     }
 
-    qprocess<OPT, NB, false, U>(a, a.nbr_ids + it.nb, it.cnt, wave_max_of_quarters(it.cnt), t, xi, Y, c0);
+    qprocess<OPT, LPI, NB, false, U>(a, a.nbr_ids + it.nb, it.cnt, wave_max_of_items<LPI>(it.cnt), t, xi, Y, c0);
     {
         const uint32_t scnt = (active && last_chunk) ? a.ns : 0u;
         const uint32_t sbase = a.bs_mode ? (row - a.batch_lo) : 0u;
-        qprocess<OPT, NB, true, U>(a, a.sample_ids + sbase, scnt, wave_max_of_quarters(scnt), t, xi, Y, c0);
+        qprocess<OPT, LPI, NB, true, U>(a, a.sample_ids + sbase, scnt, wave_max_of_items<LPI>(scnt), t, xi, Y, c0);
     }
 
     if (active) {
@@ -493,7 +500,7 @@ __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
                 v = make_float4(xi[b][0] + Y[b][0], xi[b][1] + Y[b][1], xi[b][2] + Y[b][2], xi[b][3] + Y[b][3]);  // algorithms.cpp:636
             else
                 v = make_float4(Y[b][0], Y[b][1], Y[b][2], Y[b][3]);
-            *reinterpret_cast<float4 *>(out + 64 * b) = v;
+            *reinterpret_cast<float4 *>(out + 4 * LPI * b) = v;
         }
     }
 }
