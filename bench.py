@@ -248,7 +248,7 @@ def main():
             except Exception:
                 pass
         res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": traffic, "kernel": "f2v::qstep_kernel<%d, %d, %d>" % (5 if args.option in (5, 8, 11) else 6, args.dim // 64, 8 if args.dim == 64 else 4), "algorithmic_bytes_per_launch": per_launch,
+                           "traffic": traffic, "kernel": ("f2v::qstep_kernel<%d, %d, %d, %d>" % (5 if args.option in (5, 8, 11) else 6, min(16, args.dim // 4), max(1, args.dim // 64), 4 if args.dim >= 128 else 8)) if args.dim in (16, 32, 64, 128, 256) else "f2v::step_kernel", "algorithmic_bytes_per_launch": per_launch,
                            "avg_launch_us": t_launch * 1e6, "launches": st["step_launches"]}
     if rank == 0 and world == 1:
         extra = {}
