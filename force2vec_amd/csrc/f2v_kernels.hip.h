@@ -124,20 +124,47 @@ __device__ __forceinline__ float inlane_tree(float (&t)[VEC]) {
 }
 
 // ---- row load / store ---------------------------------------------------------------------------
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float *p, float (&out)[VEC]) {
+    if constexpr (VEC == 1) {
+        out[0] = p[0];
+    } else if constexpr (VEC == 2) {
+        const float2 t = *reinterpret_cast<const float2 *>(p);
+        out[0] = t.x; out[1] = t.y;
+    } else {
+#pragma unroll
+        for (int q = 0; q < VEC / 4; ++q) {
+            const float4 t = *reinterpret_cast<const float4 *>(p + q * 4);
+            out[4 * q + 0] = t.x; out[4 * q + 1] = t.y; out[4 * q + 2] = t.z; out[4 * q + 3] = t.w;
+        }
+    }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_vec(float *p, const float (&in)[VEC]) {
+    if constexpr (VEC == 1) {
+        p[0] = in[0];
+    } else if constexpr (VEC == 2) {
+        *reinterpret_cast<float2 *>(p) = make_float2(in[0], in[1]);
+    } else {
+#pragma unroll
+        for (int q = 0; q < VEC / 4; ++q)
+            *reinterpret_cast<float4 *>(p + q * 4) = make_float4(in[4 * q + 0], in[4 * q + 1], in[4 * q + 2], in[4 * q + 3]);
+    }
+}
+
+// EXACT: D == 64*VEC, every lane owns VEC live dims.  Otherwise lanes past D hold zeros; when D is a multiple of
+// VEC (rows then stay aligned to the vector width) the live lanes still use one vector access.
 template <int VEC, bool EXACT>
 __device__ __forceinline__ void load_row(const float *src, uint32_t lane, uint32_t D, float (&out)[VEC]) {
     if constexpr (EXACT) {
-        if constexpr (VEC == 1) {
-            out[0] = src[lane];
-        } else if constexpr (VEC == 2) {
-            const float2 t = *reinterpret_cast<const float2 *>(src + lane * 2);
-            out[0] = t.x; out[1] = t.y;
+        load_vec<VEC>(src + lane * VEC, out);
+    } else if (D % VEC == 0) {
+        if (lane * VEC < D) {
+            load_vec<VEC>(src + lane * VEC, out);
         } else {
 #pragma unroll
-            for (int q = 0; q < VEC / 4; ++q) {
-                const float4 t = *reinterpret_cast<const float4 *>(src + lane * VEC + q * 4);
-                out[4 * q + 0] = t.x; out[4 * q + 1] = t.y; out[4 * q + 2] = t.z; out[4 * q + 3] = t.w;
-            }
+            for (int v = 0; v < VEC; ++v) out[v] = 0.0f;
         }
     } else {
 #pragma unroll
@@ -151,16 +178,9 @@ __device__ __forceinline__ void load_row(const float *src, uint32_t lane, uint32
 template <int VEC, bool EXACT>
 __device__ __forceinline__ void store_row(float *dst, uint32_t lane, uint32_t D, const float (&in)[VEC]) {
     if constexpr (EXACT) {
-        if constexpr (VEC == 1) {
-            dst[lane] = in[0];
-        } else if constexpr (VEC == 2) {
-            *reinterpret_cast<float2 *>(dst + lane * 2) = make_float2(in[0], in[1]);
-        } else {
-#pragma unroll
-            for (int q = 0; q < VEC / 4; ++q)
-                *reinterpret_cast<float4 *>(dst + lane * VEC + q * 4) =
-                    make_float4(in[4 * q + 0], in[4 * q + 1], in[4 * q + 2], in[4 * q + 3]);
-        }
+        store_vec<VEC>(dst + lane * VEC, in);
+    } else if (D % VEC == 0) {
+        if (lane * VEC < D) store_vec<VEC>(dst + lane * VEC, in);
     } else {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {

@@ -72,6 +72,7 @@ STEP_CASES = [
     (5, 64, 0, 4, 200, 50), (5, 100, 0, 4, 200, 50), (5, 256, 0, 16, 150, 70), (5, 512, 1, 5, 130, 33),
     (5, 3, 0, 0, 90, 90), (6, 128, 0, 512, 300, 64), (6, 128, 1, 8, 300, 64), (6, 32, 0, 3, 200, 50),
     (6, 200, 0, 7, 150, 64), (7, 128, 0, 512, 300, 64), (7, 48, 0, 512, 200, 37),
+    (5, 101, 0, 6, 120, 40), (6, 130, 1, 5, 120, 40), (5, 96, 0, 4, 150, 64), (6, 16, 0, 3, 150, 64), (5, 32, 1, 4, 150, 64),
 ]
 
 
