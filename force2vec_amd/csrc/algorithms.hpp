@@ -60,6 +60,7 @@ class algorithms {
     std::string filename, outputdir;
     double gpu_train_seconds = 0.0;  // device time of the epoch loop alone
     bool binary_output = false;      // also write "<name>.bin": raw fp32 N x D (readBinEmbeddings format)
+    bool text_output = true;         // the reference's text .embd (19 GB at 16 M x 128: switch off with -notext 1)
     f2v_stats stats{};
 
     algorithms(CSRGraph &A_csr, std::string input, std::string outputd, INDEXTYPE dim, VALUETYPE /*gamma*/, INDEXTYPE /*bsize*/, int device = 0)
@@ -90,7 +91,7 @@ class algorithms {
         std::cout << "Creating output file in following directory:" << name << std::endl;
         std::vector<float> x((size_t)rows * DIM);
         check(f2v_get_embeddings(h, x.data()));
-        check(f2v_write_embd(name, x.data(), rows, DIM));
+        if (text_output) check(f2v_write_embd(name, x.data(), rows, DIM));
         if (binary_output) check(f2v_write_embd_bin((std::string(name) + ".bin").c_str(), x.data(), rows, DIM));
     }
 

@@ -3,7 +3,7 @@
 // reference's Python scorers keep working; the parsing itself is table driven.  `-threads` and `-gamma` are
 // accepted and unused (the force kernels run on the MI355X).
 // Extra flags: -device <int>, -seed <int> (default 1 = the reference's srand(1)), -cache 1 (keep / reuse a
-// binary CSR "<input>.f2vcsr"), -binout 1 (also write "<output>.embd.bin", raw fp32 N x D), -fastrng 1
+// binary CSR "<input>.f2vcsr"), -binout 1 (also write "<output>.embd.bin", raw fp32 N x D), -notext 1, -fastrng 1
 // (NON-parity fast mode: device-side initial embeddings and option-7 walks).
 #include <cstdio>
 #include <cstdlib>
@@ -22,7 +22,7 @@ namespace {
 struct Settings {
     std::string input, output;
     long batch = 384, iter = 1200, threads = (long)std::thread::hardware_concurrency(), dim = 128, nsamples = 5, option = 5, bs = 0;
-    long device = 0, seed = 1, cache = 0, binout = 0, fastrng = 0;
+    long device = 0, seed = 1, cache = 0, binout = 0, fastrng = 0, notext = 0;
     double gamma = 1.0, lr = 0.02;
 };
 
@@ -79,6 +79,7 @@ int main(int argc, char *argv[]) {
         {"-seed", Kind::Integer, &s.seed, "<int>, srand() seed. (default:1)"},
         {"-cache", Kind::Integer, &s.cache, "<int>, 1 = keep / reuse the binary CSR <input>.f2vcsr."},
         {"-binout", Kind::Integer, &s.binout, "<int>, 1 = also write <output file>.bin, raw fp32 N x D (the scorers' binary embedding format)."},
+        {"-notext", Kind::Integer, &s.notext, "<int>, 1 = skip the text .embd (use with -binout 1 for very large graphs)."},
         {"-fastrng", Kind::Integer, &s.fastrng, "<int>, 1 = NON-PARITY fast mode: initial embeddings and option-7 walks from a device-side RNG."},
     };
     const size_t nflags = sizeof flags / sizeof flags[0];
@@ -117,6 +118,7 @@ int main(int argc, char *argv[]) {
         SetInputMatricesAsCSR(graph, s.input, s.cache != 0);
         algorithms algo(graph, s.input, s.output, (INDEXTYPE)s.dim, (VALUETYPE)s.gamma, (INDEXTYPE)s.batch, (int)s.device);
         algo.binary_output = s.binout != 0;
+        algo.text_output = s.notext == 0;
         if (s.fastrng && f2v_set_param(algo.h, "fast_rng", 1) != F2V_OK) throw std::runtime_error(f2v_last_error());
         algo.srand((unsigned)s.seed);
         std::cout << "Running: " << variant->name << std::endl;
