@@ -3,7 +3,8 @@
 // Work decomposition: a wavefront (or, in the quarter-wave layout, a 16-lane DPP row) owns one
 // source vertex (row) of the minibatch for the whole of its neighbour list:
 //   * x_i and the row's force accumulator Y_i live in registers for the whole row,
-//   * each CSR neighbour / negative sample is one coalesced row gather from HBM,
+//   * each CSR neighbour is one coalesced row gather from HBM straight into registers (read once per item);
+//     the minibatch's negative-sample rows are staged in LDS once per workgroup and shared by its items,
 //   * the squared distance (t-distribution, option 5) or dot product (sigmoid, options 6/7)
 //     is reduced in ONE canonical order -- the balanced adjacent-pair binary tree over
 //     next_pow2(D) zero-padded terms -- built from an in-lane pair tree and DPP lane-xor
@@ -466,6 +467,21 @@ __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
     const uint32_t t = lane & (LPI - 1u), q = lane / LPI;
     const uint32_t wpb = blockDim.x >> 6;
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + (threadIdx.x >> 6)));
+
+    // The minibatch's negative samples are the same ns rows for every item (except with -bs 1): the workgroup
+    // stages them in LDS once -- each CU then fetches them from L2 once per workgroup instead of once per item, and
+    // the repulsive interactions read them at LDS latency.  All lane groups of a wave read the same 16-byte
+    // slots (broadcast), consecutive lanes consecutive slots: conflict-free.
+    constexpr uint32_t kLdsSamples = 8;
+    __shared__ float4 smp[kLdsSamples][D / 4];
+    const bool lds_samples = !a.bs_mode && a.ns <= kLdsSamples;
+    if (lds_samples) {
+        for (uint32_t k = threadIdx.x; k < a.ns * (D / 4); k += blockDim.x) {
+            const uint32_t sidx = k / (D / 4), c4 = k % (D / 4);
+            smp[sidx][c4] = reinterpret_cast<const float4 *>(row_src<LPI, NB>(a, a.sample_ids[sidx]))[c4];
+        }
+        __syncthreads();
+    }
     if (IPW * w >= a.n_items) return;
 
     // this item's lanes (lane groups past the end of the list idle with cnt = 0)
@@ -505,7 +521,16 @@ __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
     }
 
     qprocess<OPT, LPI, NB, false, U>(a, a.nbr_ids + it.nb, it.cnt, wave_max_of_items<LPI>(it.cnt), t, xi, Y, c0);
-    {
+    if (lds_samples) {
+        if (active && last_chunk) {
+            for (uint32_t sidx = 0; sidx < a.ns; ++sidx) {
+                float4 xs[NB];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) xs[b] = smp[sidx][LPI * b + t];
+                pair_update_q<OPT, LPI, NB, true>(xi, xs, Y, a.lr, c0, a.sm_table);
+            }
+        }
+    } else {
         const uint32_t scnt = (active && last_chunk) ? a.ns : 0u;
         const uint32_t sbase = a.bs_mode ? (row - a.batch_lo) : 0u;
         qprocess<OPT, LPI, NB, true, U>(a, a.sample_ids + sbase, scnt, wave_max_of_items<LPI>(scnt), t, xi, Y, c0);
