@@ -152,6 +152,7 @@ def main():
 
     dist = None
     torch = None
+    host_group = None
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -167,6 +168,7 @@ def main():
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            host_group = dist.new_group(backend="gloo") if world > 1 else None  # insurance path of NcclStageComm
 
     rowptr, colids = load_graph(args.scale, 16, 1)
     n, nnz = len(rowptr) - 1, len(colids)
@@ -198,7 +200,7 @@ def main():
             comm = fdist.NeedExchange(dist, rank, world, backend="host") if args.exchange == "need" else fdist.HostStageComm(dist, rank, world)
         else:
             comm = (fdist.NeedExchange(dist, rank, world, device=local_rank, backend="device") if args.exchange == "need"
-                    else fdist.NcclStageComm(dist, rank, world, local_rank))
+                    else fdist.NcclStageComm(dist, rank, world, local_rank, host_group=host_group))
         fdist.ShardedTrainer(eng, rank, world, comm, exchange_when_single=True).train(args.option, k, batch, 5, 0.02, 0)
         s1 = eng.stats()
         st = {key: s1[key] - s0[key] for key in s1}

@@ -55,18 +55,26 @@ class _DevBuf:
 
 
 class NcclStageComm:
-    """In-place RCCL all-gather over xGMI on the new rows inside the engine's second matrix, on its HIP stream."""
+    """In-place RCCL all-gather over xGMI on the new rows inside the engine's second matrix, on its HIP stream.
 
-    def __init__(self, dist, rank, world, device):
+    Insurance for the first use on a new machine: if the very first exchange raises (an API-level refusal is the
+    same on every rank), the ranks fall back -- consistently, it is decided by the exception every one of them got --
+    to the host-bounce exchange over a gloo group created up-front; slow, but the run completes and says so."""
+
+    def __init__(self, dist, rank, world, device, host_group=None):
         import torch
         self.torch, self.dist, self.rank, self.world, self.device = torch, dist, rank, world, device
         self._views = {}
         self._stream = None
+        self._host_group = host_group
+        self._fallback = None
+        self._exchanges = 0
 
     def prepare(self, engine, max_batch_rows):
         per = -(-max_batch_rows // self.world)
         engine.stage_reserve(per * self.world)  # room for the padded all-gather
-        self._stream = self.torch.cuda.ExternalStream(engine.stream(), device=self.device)
+        if self._stream is None:
+            self._stream = self.torch.cuda.ExternalStream(engine.stream(), device=self.device)
 
     def _matrix_view(self, engine, lo):
         """torch view of the whole matrix the staged rows live in (two matrices alternate: two views, made once)."""
@@ -78,13 +86,39 @@ class NcclStageComm:
             self._views[base] = v
         return v
 
-    def exchange(self, engine, lo, hi):
+    def _device_exchange(self, engine, lo, hi):
         per, _, _ = shard_bounds(lo, hi, self.rank, self.world)
         d = engine.dim
         full = self._matrix_view(engine, lo)[lo * d: (lo + per * self.world) * d]
         mine = full[self.rank * per * d: (self.rank + 1) * per * d]
         with self.torch.cuda.stream(self._stream):
             self.dist.all_gather_into_tensor(full, mine)
+
+    def exchange(self, engine, lo, hi):
+        if self._fallback is not None:
+            return self._fallback.exchange(engine, lo, hi)
+        self._exchanges += 1
+        if self._exchanges > 1 or self._host_group is None:
+            return self._device_exchange(engine, lo, hi)
+        try:
+            self._device_exchange(engine, lo, hi)
+            engine.synchronize()
+            self.torch.cuda.synchronize()
+        except Exception as ex:  # noqa: BLE001 -- see the class docstring
+            import sys
+            print("force2vec_amd.dist: RCCL exchange refused (%r); falling back to the host-bounce exchange" % (ex,), file=sys.stderr, flush=True)
+            self._fallback = HostStageComm(_GroupDist(self.dist, self._host_group), self.rank, self.world)
+            self._fallback.exchange(engine, lo, hi)
+
+
+class _GroupDist:
+    """torch.distributed restricted to one process group (what HostStageComm calls)."""
+
+    def __init__(self, dist, group):
+        self._dist, self._group = dist, group
+
+    def all_gather(self, out, inp):
+        return self._dist.all_gather(out, inp, group=self._group)
 
 
 def row_owner(n, batch, world):

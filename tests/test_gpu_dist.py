@@ -47,6 +47,15 @@ def _gloo_worker(rank, world, port, case, outdir, exchange="allgather"):
         comm = fdist.HostStageComm(dist, rank, world)
     elif exchange == "need":
         comm = fdist.NeedExchange(dist, rank, world, backend="host")
+    elif exchange == "nccl_refused":
+        # the insurance path of NcclStageComm: the device exchange raises on first use -> host bounce over the gloo group
+        import torch
+        torch.cuda.set_device(0)
+        comm = fdist.NcclStageComm(dist, rank, world, 0, host_group=dist.group.WORLD)
+
+        def refuse(*a, **k):
+            raise RuntimeError("simulated RCCL refusal")
+        comm._device_exchange = refuse
     else:  # device-side pack / unpack on the engine's stream, collectives bounced through the host (gloo)
         import torch
         torch.cuda.set_device(0)
@@ -58,7 +67,7 @@ def _gloo_worker(rank, world, port, case, outdir, exchange="allgather"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["need", "need_device"])
+@pytest.mark.parametrize("mode", ["need", "need_device", "nccl_refused"])
 @pytest.mark.parametrize("case", [("cora.mtx", 5, 3, 256, 128, 0), ("cora.mtx", 6, 2, 300, 64, 1)])
 def test_two_gloo_ranks_per_destination_exchange(case, mode, tmp_path):
     """The same with NeedExchange: rows travel only to the ranks that read them, replicas are completed at the end.
