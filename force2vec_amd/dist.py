@@ -8,8 +8,10 @@ and ONE exchange per minibatch -- an all-gather of the staged new rows, B x D fp
 makes every replica identical again.  Results are bit-identical to the single-GPU run for any
 world size.  Every rank draws the same rand() stream on its host.
 
-The exchange is an in-place RCCL all-gather on those rows of the second matrix (torch.distributed backend
-"nccl", zero-copy on the engine's own HIP stream); a host-bounce variant serves gloo."""
+Three interchangeable exchanges, all bit-identical in result: NcclStageComm (default: an in-place RCCL all-gather
+on those rows of the second matrix, zero-copy on the engine's own HIP stream), HostStageComm (the same through
+host memory: gloo, tests, and NcclStageComm's insurance path) and NeedExchange (per-destination all-to-all-v:
+a rank receives only the rows it reads)."""
 import numpy as np
 
 
