@@ -425,7 +425,7 @@ __device__ __forceinline__ const float *row_src(const StepArgs &a, uint32_t j) {
 // fetched one group ahead.
 template <int OPT, int LPI, int NB, bool NEG, int U>
 __device__ __forceinline__ void qprocess(const StepArgs &a, const uint32_t *ids, uint32_t cnt, uint32_t maxcnt, uint32_t t,
-                                         const float (&xi)[NB][4], float (&Y)[NB][4], double c0) {
+                                         const float (&xi)[NB][4], float (&Y)[NB][4], double c0, const float *table) {
     uint32_t j[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) j[u] = ((uint32_t)u < cnt) ? ids[u] : 0u;
@@ -443,7 +443,7 @@ __device__ __forceinline__ void qprocess(const StepArgs &a, const uint32_t *ids,
         for (int u = 0; u < U; ++u) j[u] = (g + U + u < cnt) ? ids[g + U + u] : 0u;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (g + u < cnt) pair_update_q<OPT, LPI, NB, NEG>(xi, xj[u], Y, a.lr, c0, a.sm_table);
+            if (g + u < cnt) pair_update_q<OPT, LPI, NB, NEG>(xi, xj[u], Y, a.lr, c0, table);
         }
     }
 }
@@ -475,13 +475,20 @@ __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
     constexpr uint32_t kLdsSamples = 8;
     __shared__ float4 smp[kLdsSamples][D / 4];
     const bool lds_samples = !a.bs_mode && a.ns <= kLdsSamples;
+    // options 6/7: the 8-KiB sigmoid table is looked up once per interaction, in the middle of the dependent chain
+    // dot product -> sigma -> update; from LDS that lookup costs ~64 cycles instead of an L1/L2 round trip
+    __shared__ float sm_lds[OPT == 5 ? 1 : 2048];
+    if constexpr (OPT != 5) {
+        for (uint32_t k = threadIdx.x; k < 2048u; k += blockDim.x) sm_lds[k] = a.sm_table[k];
+    }
     if (lds_samples) {
         for (uint32_t k = threadIdx.x; k < a.ns * (D / 4); k += blockDim.x) {
             const uint32_t sidx = k / (D / 4), c4 = k % (D / 4);
             smp[sidx][c4] = reinterpret_cast<const float4 *>(row_src<LPI, NB>(a, a.sample_ids[sidx]))[c4];
         }
-        __syncthreads();
     }
+    if (lds_samples || OPT != 5) __syncthreads();
+    const float *table = OPT == 5 ? a.sm_table : sm_lds;
     if (IPW * w >= a.n_items) return;
 
     // this item's lanes (lane groups past the end of the list idle with cnt = 0)
@@ -520,20 +527,20 @@ __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
         c0 = (double)(a.lr * degi);
     }
 
-    qprocess<OPT, LPI, NB, false, U>(a, a.nbr_ids + it.nb, it.cnt, wave_max_of_items<LPI>(it.cnt), t, xi, Y, c0);
+    qprocess<OPT, LPI, NB, false, U>(a, a.nbr_ids + it.nb, it.cnt, wave_max_of_items<LPI>(it.cnt), t, xi, Y, c0, table);
     if (lds_samples) {
         if (active && last_chunk) {
             for (uint32_t sidx = 0; sidx < a.ns; ++sidx) {
                 float4 xs[NB];
 #pragma unroll
                 for (int b = 0; b < NB; ++b) xs[b] = smp[sidx][LPI * b + t];
-                pair_update_q<OPT, LPI, NB, true>(xi, xs, Y, a.lr, c0, a.sm_table);
+                pair_update_q<OPT, LPI, NB, true>(xi, xs, Y, a.lr, c0, table);
             }
         }
     } else {
         const uint32_t scnt = (active && last_chunk) ? a.ns : 0u;
         const uint32_t sbase = a.bs_mode ? (row - a.batch_lo) : 0u;
-        qprocess<OPT, LPI, NB, true, U>(a, a.sample_ids + sbase, scnt, wave_max_of_items<LPI>(scnt), t, xi, Y, c0);
+        qprocess<OPT, LPI, NB, true, U>(a, a.sample_ids + sbase, scnt, wave_max_of_items<LPI>(scnt), t, xi, Y, c0, table);
     }
 
     if (active) {
