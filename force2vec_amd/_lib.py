@@ -61,6 +61,8 @@ SIGNATURES = {
     "f2v_rng_create": (C.c_void_p, [C.c_uint32]),
     "f2v_rng_destroy": (None, [C.c_void_p]),
     "f2v_rng_next": (C.c_int, [C.c_void_p]),
+    "f2v_rng_jump": (None, [C.c_void_p, C.c_uint64]),
+    "f2v_rng_fill": (C.c_int, [C.c_void_p, f32p, C.c_uint64, C.c_int]),
     "f2v_sm_table": (C.c_int, [f32p]),
     "f2v_test_gather_calibration": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32]),
     "f2v_test_wave_reduce": (C.c_int, [C.c_int, f32p, C.c_uint32, C.c_uint32, f32p]),

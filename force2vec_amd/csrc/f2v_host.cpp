@@ -50,12 +50,87 @@ void Rand::seed(uint32_t s) {
     for (int i = 0; i < 310; i++) next();
 }
 
-void init_embeddings_host(Rand &g, float *x, size_t total, int kind) {
+namespace {
+
+using Mat = std::vector<uint32_t>;  // 31 x 31, row-major, arithmetic mod 2^32
+
+Mat mat_mul(const Mat &a, const Mat &b) {
+    Mat c(31 * 31, 0u);
+    for (int i = 0; i < 31; i++)
+        for (int k = 0; k < 31; k++) {
+            const uint32_t aik = a[i * 31 + k];
+            if (!aik) continue;
+            for (int j = 0; j < 31; j++) c[i * 31 + j] += aik * b[k * 31 + j];
+        }
+    return c;
+}
+
+// v = (x[i-31], ..., x[i-1]);  one draw: v' = (v[1..30], v[0] + v[28])
+Mat step_matrix_pow(uint64_t k) {
+    Mat result(31 * 31, 0u), base(31 * 31, 0u);
+    for (int i = 0; i < 31; i++) result[i * 31 + i] = 1u;
+    for (int i = 0; i < 30; i++) base[i * 31 + i + 1] = 1u;
+    base[30 * 31 + 0] = 1u;
+    base[30 * 31 + 28] = 1u;
+    while (k) {
+        if (k & 1) result = mat_mul(base, result);
+        base = mat_mul(base, base);
+        k >>= 1;
+    }
+    return result;
+}
+
+void apply_matrix(const Mat &m, Rand &g) {
+    uint32_t v[31], w[31];
+    for (int k = 0; k < 31; k++) v[k] = (uint32_t)g.r[(g.f + k) % 31];  // oldest first
+    for (int i = 0; i < 31; i++) {
+        uint32_t acc = 0;
+        for (int j = 0; j < 31; j++) acc += m[i * 31 + j] * v[j];
+        w[i] = acc;
+    }
+    for (int k = 0; k < 31; k++) g.r[k] = (int32_t)w[k];
+    g.f = 0;
+    g.b = 28;
+}
+
+inline void fill(Rand &g, float *x, size_t count, int kind) {
     // double arithmetic narrowed on store, as `-1.0 + 2.0 * rand()/(RAND_MAX+1.0)` compiles
     if (kind == F2V_INIT_SYMMETRIC)
-        for (size_t k = 0; k < total; k++) x[k] = (float)(-1.0 + 2.0 * (double)g.next() / 2147483648.0);
+        for (size_t k = 0; k < count; k++) x[k] = (float)(-1.0 + 2.0 * (double)g.next() / 2147483648.0);
     else
-        for (size_t k = 0; k < total; k++) x[k] = (float)((double)g.next() / 2147483648.0);
+        for (size_t k = 0; k < count; k++) x[k] = (float)((double)g.next() / 2147483648.0);
+}
+
+}  // namespace
+
+void Rand::jump(uint64_t k) {
+    if (k) apply_matrix(step_matrix_pow(k), *this);
+}
+
+// randInitF / randInit: N*D draws of the ONE serial rand() stream.  The stream is cut into equal chunks whose start
+// states come from Rand::jump, the chunks are filled by threads, and `g` leaves exactly as after `total` serial draws.
+void init_embeddings_host(Rand &g, float *x, size_t total, int kind) {
+    unsigned T = std::thread::hardware_concurrency();
+    if (const char *e = getenv("F2V_IO_THREADS")) T = (unsigned)atoi(e);
+    T = std::max(1u, std::min(T, 64u));
+    if (total < (size_t)(1u << 20) || T == 1) {
+        fill(g, x, total, kind);
+        return;
+    }
+    const size_t chunk = (total + T - 1) / T;
+    const Mat m = step_matrix_pow(chunk);
+    std::vector<Rand> start(T, g);
+    for (unsigned t = 1; t < T; t++) {
+        start[t] = start[t - 1];
+        apply_matrix(m, start[t]);
+    }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; t++) {
+        const size_t lo = std::min(total, (size_t)t * chunk), hi = std::min(total, lo + chunk);
+        th.emplace_back([&, t, lo, hi] { fill(start[t], x + lo, hi - lo, kind); });
+    }
+    for (auto &y : th) y.join();
+    g.jump(total);
 }
 
 void sm_table_host(float *t) {
@@ -82,6 +157,12 @@ f2v_rng *f2v_rng_create(uint32_t seed) {
 }
 void f2v_rng_destroy(f2v_rng *g) { delete reinterpret_cast<Rand *>(g); }
 int f2v_rng_next(f2v_rng *g) { return reinterpret_cast<Rand *>(g)->next(); }
+void f2v_rng_jump(f2v_rng *g, uint64_t k) { reinterpret_cast<Rand *>(g)->jump(k); }
+int f2v_rng_fill(f2v_rng *g, float *out, uint64_t count, int kind) {
+    if (!g || (!out && count) || (kind != F2V_INIT_SYMMETRIC && kind != F2V_INIT_UNIT)) return fail(F2V_EINVAL, "f2v_rng_fill: bad argument");
+    init_embeddings_host(*reinterpret_cast<Rand *>(g), out, (size_t)count, kind);
+    return F2V_OK;
+}
 
 int f2v_sm_table(float *t) {
     if (!t) return fail(F2V_EINVAL, "f2v_sm_table: null output");

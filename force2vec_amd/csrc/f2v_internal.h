@@ -27,6 +27,10 @@ struct Rand {
     }
     // randIndex(max,min), sample/algorithms.cpp:55-58
     inline uint32_t index(uint32_t max_num, uint32_t min_num) { return ((uint32_t)next() % (max_num - min_num)) + min_num; }
+    // Advance the stream by `k` draws in O(31^3 log k): x[i] = x[i-31] + x[i-3] (mod 2^32) is linear, so k steps are
+    // one 31x31 matrix over Z/2^32 applied to the 31-word state.  This is what lets N*D draws be made in parallel
+    // (and bit-identically to the serial stream).
+    void jump(uint64_t k);
 };
 
 void init_embeddings_host(Rand &g, float *x, size_t total, int kind);

@@ -170,6 +170,11 @@ typedef struct f2v_rng f2v_rng;
 f2v_rng *f2v_rng_create(uint32_t seed);
 void f2v_rng_destroy(f2v_rng *g);
 int f2v_rng_next(f2v_rng *g);
+/* Skip k draws in O(log k) (the generator is linear: a 31x31 matrix over Z/2^32 per jump). */
+void f2v_rng_jump(f2v_rng *g, uint64_t k);
+/* `count` values as randInitF (kind 0) / randInit (kind 1) would store them, drawn from ONE serial stream but filled
+ * in parallel from jump-ahead states; the stream ends where `count` serial draws would leave it. */
+int f2v_rng_fill(f2v_rng *g, float *out, uint64_t count, int kind);
 
 /* The 2048-entry sigmoid table of init_SM_TABLE (sample/algorithms.cpp:757-764) as the source defines it. */
 int f2v_sm_table(float *table_out /* 2048 */);

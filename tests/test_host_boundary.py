@@ -169,3 +169,29 @@ def test_header_is_plain_c_and_links(tmp_path):
                            "-L", libdir, "-lf2v", "-Wl,-rpath," + libdir])
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.startswith("1804289383 f2v-mi355x"), out.stdout + out.stderr
+
+
+def test_parallel_init_equals_the_serial_rand_stream():
+    """N*D initial values are draws of ONE serial rand() stream; libf2v cuts it into chunks with a 31x31 jump-ahead
+    matrix (the generator is linear over Z/2^32) and fills them with threads -- same bits as the serial draw, same
+    stream position afterwards."""
+    L = _lib.lib()
+    libc = C.CDLL("libc.so.6")
+    for k in (0, 1, 2, 30, 31, 32, 1000, 123457):
+        g = L.f2v_rng_create(5)
+        L.f2v_rng_jump(g, k)
+        libc.srand(5)
+        for _ in range(k):
+            libc.rand()
+        assert [L.f2v_rng_next(g) for _ in range(40)] == [libc.rand() for _ in range(40)], k
+        L.f2v_rng_destroy(g)
+    for kind in (0, 1):
+        for count in (1000, (1 << 20) + 12345, 3000001):  # below and above the parallel threshold, ragged chunks
+            g = L.f2v_rng_create(1)
+            out = np.empty(count, dtype=np.float32)
+            _lib.check(L.f2v_rng_fill(g, out.ctypes.data_as(_lib.f32p), count, kind))
+            o = O.Rng(1)
+            want = o.init_embeddings(1, count, kind)[0]
+            assert np.array_equal(out, want), (kind, count)
+            assert L.f2v_rng_next(g) == o.rand()
+            L.f2v_rng_destroy(g)
