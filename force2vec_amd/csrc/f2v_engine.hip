@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <tuple>
 #include <type_traits>
@@ -504,12 +505,12 @@ int f2v_init_embeddings(f2v_handle c, int kind) {
         c->have_x = true;
         return F2V_OK;
     }
-    std::vector<float> x(total);
-    init_embeddings_host(c->rng, x.data(), total, kind);
+    std::unique_ptr<float[]> x(new float[total]);  // not value-initialised: the fill threads are the first to touch it
+    init_embeddings_host(c->rng, x.get(), total, kind);
     HIPC(hipStreamSynchronize(c->stream));
     c->pending = false;
     c->upd_lo = c->upd_hi = 0;
-    HIPC(hipMemcpy(c->d_X[c->cur], x.data(), total * sizeof(float), hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(c->d_X[c->cur], x.get(), total * sizeof(float), hipMemcpyHostToDevice));
     c->have_x = true;
     return F2V_OK;
 }
