@@ -7,8 +7,12 @@ One "step" = one epoch = one pass of the hot path over every minibatch of the sy
 graph (BASELINE.json configs[2]: RMAT scale-20, ~1 M vertices / ~16 M undirected edges,
 option 5, D = 128, ns = 5).  edges/sec = nnz * K / T (nnz = directed CSR nonzeros, the
 reference's unit).  Inputs are resident in HBM when the timed region starts.
-N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL): the SAME graph and
-epochs, each minibatch's rows sharded over the ranks (force2vec_amd/dist.py) -- strong scaling.
+N > 1 (launched by torch.distributed.run, one rank per GPU): the SAME graph and epochs, each
+minibatch's rows sharded over the ranks -- strong scaling.  Default exchange: the engine's push over
+xGMI (f2v_train_sharded: new rows stored straight into the reading peers' HBM, device-side flag
+barrier; torch.distributed only carries the IPC handles); if it cannot be set up on this machine the
+run falls back to an RCCL all-gather per minibatch and says so.  After the timed region every rank
+checks its replica bit for bit against a single-GPU run of the same epochs.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` (HBM bound,
 algorithmic bytes / launch over the live HIP-event launch time) and `cpu_baseline` (the genuine
@@ -131,8 +135,10 @@ def main():
     ap.add_argument("--cpu-scale", type=int, default=17)
     ap.add_argument("--cpu-iters", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--exchange", choices=["allgather", "need"], default="allgather",
-                    help="N>1: all-gather of every minibatch's new rows, or per-destination sends of only the rows each rank reads")
+    ap.add_argument("--exchange", choices=["push", "allgather", "need"], default="push",
+                    help="N>1: push = the engine's own xGMI exchange (rows stored into the reading peers' HBM by a HIP kernel); "
+                         "allgather = RCCL all-gather of every minibatch's new rows; need = RCCL all-to-all-v of only the rows each rank reads")
+    ap.add_argument("--no-verify", action="store_true", help="N>1: skip the bit-for-bit check of every replica against a single-GPU run")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: self-test of the N>1 plumbing on a one-GPU box (all ranks on device 0, exchange through the host)")
     ap.add_argument("--force-dist", action="store_true", help="drive even a single rank through the multi-GPU path (RCCL group of 1): self-test")
@@ -190,20 +196,43 @@ def main():
             if args.dist_backend == "nccl":
                 torch.cuda.synchronize()
 
+    state = {"exchange": args.exchange, "comm": None, "note": None}
+
+    def make_comm():
+        """The exchange this run uses; the push exchange is attached (and self-tested) here, once."""
+        if state["comm"] is not None:
+            return state["comm"]
+        ex = state["exchange"]
+        if ex == "push":
+            comm = fdist.PushExchange(dist, rank, world, group=host_group)
+            try:
+                comm.attach(eng)
+            except Exception as exn:  # raised on every rank alike (the ranks agree inside attach)
+                state["note"] = "push exchange unavailable (%s): fell back to the RCCL all-gather" % (str(exn)[:200],)
+                log("bench[rank %d]: %s" % (rank, state["note"]))
+                state["exchange"] = ex = "allgather"
+        if ex == "allgather":
+            comm = (fdist.HostStageComm(dist, rank, world) if args.dist_backend == "gloo"
+                    else fdist.NcclStageComm(dist, rank, world, local_rank, host_group=host_group))
+        elif ex == "need":
+            comm = (fdist.NeedExchange(dist, rank, world, backend="host") if args.dist_backend == "gloo"
+                    else fdist.NeedExchange(dist, rank, world, device=local_rank, backend="device"))
+        state["comm"] = comm
+        return comm
+
     def run_epochs(k, batch):
         """-> per-rank statistics of these k epochs (launches, algorithmic bytes, device seconds where known)."""
         if not use_dist:
             eng.train(args.option, k, batch, 5, 0.02, 0)
             return eng.stats()
         s0 = eng.stats()
-        if args.dist_backend == "gloo":
-            comm = fdist.NeedExchange(dist, rank, world, backend="host") if args.exchange == "need" else fdist.HostStageComm(dist, rank, world)
-        else:
-            comm = (fdist.NeedExchange(dist, rank, world, device=local_rank, backend="device") if args.exchange == "need"
-                    else fdist.NcclStageComm(dist, rank, world, local_rank, host_group=host_group))
+        comm = make_comm()
         fdist.ShardedTrainer(eng, rank, world, comm, exchange_when_single=True).train(args.option, k, batch, 5, 0.02, 0)
         s1 = eng.stats()
-        st = {key: s1[key] - s0[key] for key in s1}
+        if state["exchange"] == "push":
+            st = dict(s1)  # f2v_train_sharded restarts the statistics like f2v_train
+        else:
+            st = {key: s1[key] - s0[key] for key in s1}
         st["device_seconds"] = None  # the sharded loop is timed by the wall clock below
         return st
 
@@ -221,7 +250,35 @@ def main():
             dt = float(t.item())
         return dt, st
 
+    def verify(schedule):
+        """Every rank: the same epochs on ONE engine (no sharding, no exchange) must give this replica bit for bit."""
+        ref = F.Engine(rowptr, colids, args.dim, device=local_rank)
+        ref.set_param("hub_chunk", eng.get_param("hub_chunk"))  # the chunk is part of the summation order
+        ref.srand(1)
+        ref.init_embeddings(F._lib.INIT_SYMMETRIC if args.option in (5, 8, 11) else F._lib.INIT_UNIT)
+        for k in schedule:
+            ref.train(args.option, k, args.batch, 5, 0.02, 0)
+        same = bool(np.array_equal(ref.get_embeddings(), eng.get_embeddings()))
+        ref.close()
+        t = torch.tensor([1 if same else 0], dtype=torch.int32, device="cuda" if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
     dt, st = timed(args.steps, args.warmup, args.batch)
+    verified = None
+    if use_dist and not args.no_verify:
+        schedule = ([args.warmup] if args.warmup > 0 else []) + [args.steps]
+        verified = verify(schedule)
+        if not verified and state["exchange"] == "push":
+            # never report a number for wrong results: redo the whole measurement over the RCCL all-gather
+            state["note"] = "push exchange gave a replica that differs from the single-GPU run: measured again over the RCCL all-gather"
+            log("bench[rank %d]: %s" % (rank, state["note"]))
+            state["comm"].detach(eng)
+            state["comm"], state["exchange"] = None, "allgather"
+            eng.srand(1)
+            eng.init_embeddings(F._lib.INIT_SYMMETRIC if args.option in (5, 8, 11) else F._lib.INIT_UNIT)
+            dt, st = timed(args.steps, args.warmup, args.batch)
+            verified = verify(schedule)
     value = nnz * args.steps / dt
     res = {
         "metric": "embedding edges/sec at D=%d, option %d" % (args.dim, args.option),
@@ -231,8 +288,19 @@ def main():
         "config": {"workload": "RMAT scale-%d edge-factor 16 (n=%d, nnz=%d directed CSR nonzeros), option %d, D=%d, ns=5, lr=0.02, batch=%d; step = 1 epoch"
                    % (args.scale, n, nnz, args.option, args.dim, args.batch),
                    "batch": args.batch, "hub_chunk": eng.get_param("hub_chunk"),
-                   "parallelism": "1 GPU" if world == 1 else "minibatch rows sharded over %d GPUs, replicated graph+matrix, %s %s of the new rows" % (world, "RCCL" if args.dist_backend == "nccl" else "gloo (host-bounce self-test)", "all-gather" if args.exchange == "allgather" else "all-to-all-v (per-destination)")},
+                   "parallelism": "1 GPU" if not use_dist else "minibatch rows sharded over %d GPUs, replicated graph+matrix, %s" % (world, {
+                       "push": "new rows pushed over xGMI into the HBM of the peers that read them (HIP kernel + device-side flag barrier)",
+                       "allgather": "%s all-gather of the new rows" % ("RCCL" if args.dist_backend == "nccl" else "gloo (host-bounce self-test)"),
+                       "need": "%s all-to-all-v of the rows each rank reads" % ("RCCL" if args.dist_backend == "nccl" else "gloo (host-bounce self-test)")}[state["exchange"]])},
     }
+    if use_dist:
+        res["config"]["exchange"] = state["exchange"]
+        res["config"]["replicas_bit_identical_to_1gpu_run"] = verified
+        if state["note"]:
+            res["config"]["note"] = state["note"]
+        if state["exchange"] == "push":
+            ps = eng.push_stats()
+            res["config"]["rows_pushed_over_allgather_rows"] = ps["rows_pushed"] / max(ps["rows_allgather"], 1)
     if st is not None:
         # dominant kernel = qstep_kernel, one launch per minibatch; launch time from HIP events on the
         # engine's stream around the epoch loop (f2v_train), algorithmic bytes per SURVEY 8d.
@@ -252,7 +320,7 @@ def main():
         res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                            "traffic": traffic, "kernel": ("f2v::qstep_kernel<%d, %d, %d, %d>" % (5 if args.option in (5, 8, 11) else 6, min(16, args.dim // 4), max(1, args.dim // 64), 4 if args.dim >= 128 else 8)) if args.dim in (16, 32, 64, 128, 256) else "f2v::step_kernel", "algorithmic_bytes_per_launch": per_launch,
                            "avg_launch_us": t_launch * 1e6, "launches": st["step_launches"]}
-    if rank == 0 and world == 1:
+    if rank == 0 and not use_dist:
         extra = {}
         for b in [int(x) for x in args.extra_batches.split(",") if x]:
             dtb, stb = timed(max(1, args.steps // 2), 1, b)
@@ -261,11 +329,13 @@ def main():
                                      "hbm_GBs": stb["algorithmic_bytes"] / stb["device_seconds"] * 1e-9}
         if extra:
             res["extra"] = extra
-        if not args.no_cpu_baseline:
-            try:
-                res["cpu_baseline"] = cpu_baseline(args)
-            except Exception as ex:  # the baseline is reported, never required for the GPU number
-                res["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": os.cpu_count(), "kind": "reference", "sample": "failed: %r" % (ex,)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            res["cpu_baseline"] = cpu_baseline(args)
+        except Exception as ex:  # the baseline is reported, never required for the GPU number
+            res["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": os.cpu_count(), "kind": "reference", "sample": "failed: %r" % (ex,)}
+    if use_dist and state["exchange"] == "push" and state["comm"] is not None:
+        state["comm"].detach(eng)
     eng.close()
     if use_dist:
         dist.barrier()

@@ -51,6 +51,13 @@ SIGNATURES = {
     "f2v_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "f2v_synchronize": (C.c_int, [C.c_void_p]),
     "f2v_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "f2v_push_export": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "f2v_push_attach": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "f2v_push_selftest": (C.c_int, [C.c_void_p]),
+    "f2v_push_detach": (C.c_int, [C.c_void_p]),
+    "f2v_train_sharded": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_int, C.POINTER(C.c_double)]),
+    "f2v_push_masks": (C.c_int, [u32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32, u32p, C.c_uint64, u32p]),
+    "f2v_push_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "f2v_read_mtx": (C.c_int, [C.c_char_p, u32p, C.POINTER(C.c_uint64), C.POINTER(u32p), C.POINTER(u32p)]),
     "f2v_free": (None, [C.c_void_p]),
     "f2v_write_embd": (C.c_int, [C.c_char_p, f32p, C.c_uint32, C.c_uint32]),
@@ -64,9 +71,13 @@ SIGNATURES = {
     "f2v_rng_jump": (None, [C.c_void_p, C.c_uint64]),
     "f2v_rng_fill": (C.c_int, [C.c_void_p, f32p, C.c_uint64, C.c_int]),
     "f2v_sm_table": (C.c_int, [f32p]),
+    "f2v_test_push_attach_local": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
     "f2v_test_gather_calibration": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32]),
     "f2v_test_wave_reduce": (C.c_int, [C.c_int, f32p, C.c_uint32, C.c_uint32, f32p]),
 }
+
+PUSH_EXPORT_BYTES = 256  # F2V_PUSH_EXPORT_BYTES
+PUSH_MAX_RANKS = 8       # F2V_PUSH_MAX_RANKS
 
 _lib = None
 

@@ -46,6 +46,16 @@ struct Plan {
     uint64_t nnz = 0;
 };
 
+// what a rank hands its peers (f2v_push_export): F2V_PUSH_EXPORT_BYTES bytes
+struct PushExport {
+    hipIpcMemHandle_t x[2], flags;
+    uint32_t magic, n, D, cur;
+    char reserved[F2V_PUSH_EXPORT_BYTES - 3 * sizeof(hipIpcMemHandle_t) - 16];
+};
+static_assert(sizeof(PushExport) == F2V_PUSH_EXPORT_BYTES, "export blob layout");
+static_assert(kMaxRanks == F2V_PUSH_MAX_RANKS, "rank limit");
+constexpr uint32_t kPushMagic = 0x46325650u;  // "F2VP"
+
 struct f2v_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -81,6 +91,22 @@ struct f2v_ctx {
     int rows_in_flight = 4;
     bool use_graph = false;  // f2v_train replays one hipGraph per epoch parity instead of launching eagerly
     f2v_stats stats{};
+    // multi-GPU push exchange (include/f2v.h): peers' matrices and flags mapped through HIP IPC
+    struct Push {
+        bool exported = false, attached = false, local = false;  // local: peers are handles of this process (self-test)
+        uint32_t rank = 0, world = 1;
+        float *peer_X[2][kMaxRanks] = {};
+        unsigned long long *flags = nullptr, *peer_flags[kMaxRanks] = {};
+        uint32_t *d_err = nullptr;
+        unsigned long long seq = 0;
+        int64_t timeout_ms = 20000;
+        // reader masks: neighbour part cached per (batch, world), sampled vertices patched in per run
+        std::vector<uint32_t> base_masks, patched_ids;
+        uint32_t mask_batch = 0, mask_world = 0;
+        uint32_t *d_masks = nullptr, *d_patch = nullptr;
+        size_t patch_cap = 0;
+        uint64_t pushed_per_epoch = 0, rows_pushed = 0, rows_allgather = 0;
+    } push;
 };
 
 namespace {
@@ -95,7 +121,7 @@ int pick_vec(uint32_t D) {
 // 0.6 us per neighbour), the launch as a whole streams ~516 B per nonzero at ~6 TB/s; keeping the
 // longest stretch at about half the launch's streaming time gives chunk ~ batch nonzeros / 14000
 // (measured optimum on RMAT-20: 16 at B=4096, 32 at B=16384, 128 at B=65536).  It depends only on
-// the graph and the batch size, never on the number of ranks, so results do not change with -gpus.
+// the graph and the number of rows one launch covers (the batch, or a rank's slice of it in f2v_train_sharded).
 uint32_t auto_chunk(const f2v_ctx *c, uint32_t batch) {
     const double est = (double)std::min(batch, c->n) * ((double)c->nnz / (double)c->n) / 14000.0;
     uint32_t ch = 8;
@@ -402,6 +428,128 @@ void generate_walks_host(f2v_ctx *c, std::vector<uint32_t> &walks) {
     }
 }
 
+// ---- push exchange helpers (include/f2v.h) ---------------------------------------------------------------
+// slice of rank r of minibatch [lo,hi): contiguous, equal (the same rule as force2vec_amd/dist.py shard_bounds)
+void shard_of(uint32_t lo, uint32_t hi, uint32_t rank, uint32_t world, uint32_t *my_lo, uint32_t *my_hi) {
+    const uint32_t per = (hi - lo + world - 1) / world;
+    *my_lo = (uint32_t)std::min<uint64_t>((uint64_t)lo + (uint64_t)rank * per, hi);
+    *my_hi = (uint32_t)std::min<uint64_t>((uint64_t)*my_lo + per, hi);
+}
+
+// copy my rows [row_lo,row_hi) of matrix `which` into the same matrix of the peers that read them
+int launch_push(f2v_ctx *c, int which, const uint32_t *d_masks, uint32_t row_lo, uint32_t row_hi) {
+    if (c->push.world < 2 || row_hi <= row_lo) return F2V_OK;
+    PushArgs a{};
+    a.src = c->d_X[which];
+    for (uint32_t r = 0; r < c->push.world; r++) a.peer[r] = c->push.peer_X[which][r];
+    a.masks = d_masks;
+    a.row_lo = row_lo;
+    a.rows = row_hi - row_lo;
+    a.D = c->D;
+    a.self = c->push.rank;
+    a.world = c->push.world;
+    const uint32_t wpb = 4;
+    const uint32_t blocks = std::min<uint32_t>((a.rows + wpb - 1) / wpb, 2048u);
+    int rc = dispatch_layout(c, [&](auto V, auto E) {
+        hipLaunchKernelGGL((push_rows_kernel<decltype(V)::value, decltype(E)::value>), dim3(blocks), dim3(64 * wpb), 0, c->stream, a);
+    });
+    if (rc != F2V_OK) return rc;
+    HIPC(hipGetLastError());
+    return F2V_OK;
+}
+
+int launch_barrier(f2v_ctx *c) {
+    if (c->push.world < 2) return F2V_OK;
+    BarrierArgs b{};
+    b.flags = c->push.flags;
+    for (uint32_t r = 0; r < c->push.world; r++) b.peer_flags[r] = c->push.peer_flags[r];
+    b.err = c->push.d_err;
+    b.seq = ++c->push.seq;
+    b.timeout_ticks = (unsigned long long)c->push.timeout_ms * 100000ull;  // wall_clock64 ticks at 100 MHz
+    b.self = c->push.rank;
+    b.world = c->push.world;
+    hipLaunchKernelGGL(xgmi_barrier_kernel, dim3(1), dim3(64), 0, c->stream, b);
+    HIPC(hipGetLastError());
+    return F2V_OK;
+}
+
+// after a stream synchronisation: did every barrier see all peers?
+int check_push_err(f2v_ctx *c, const char *where) {
+    if (c->push.world < 2) return F2V_OK;
+    uint32_t e = 0;
+    HIPC(hipMemcpy(&e, c->push.d_err, sizeof e, hipMemcpyDeviceToHost));
+    if (e) return fail(F2V_ESTATE, "%s: a peer did not reach the xGMI barrier within %lld ms", where, (long long)c->push.timeout_ms);
+    return F2V_OK;
+}
+
+int push_detach(f2v_ctx *c) {
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->push.attached && !c->push.local) {
+        for (uint32_t r = 0; r < c->push.world; r++) {
+            if (r == c->push.rank) continue;
+            for (int k = 0; k < 2; k++)
+                if (c->push.peer_X[k][r]) (void)hipIpcCloseMemHandle(c->push.peer_X[k][r]);
+            if (c->push.peer_flags[r]) (void)hipIpcCloseMemHandle(c->push.peer_flags[r]);
+        }
+    }
+    for (int k = 0; k < 2; k++)
+        for (int r = 0; r < kMaxRanks; r++) c->push.peer_X[k][r] = nullptr;
+    for (int r = 0; r < kMaxRanks; r++) c->push.peer_flags[r] = nullptr;
+    c->push.attached = false;
+    c->push.local = false;
+    c->push.rank = 0;
+    c->push.world = 1;
+    return F2V_OK;
+}
+
+// Reader masks of this run in HBM: the neighbour part is static per (batch, world) and cached; the vertices this
+// run samples are read by everyone and are patched in (and last run's patched out) by two scatter launches.
+int prepare_masks(f2v_ctx *c, uint32_t batch, const std::vector<uint32_t> &ids) {
+    auto &P = c->push;
+    if (P.mask_batch != batch || P.mask_world != P.world || P.base_masks.size() != c->n || !P.d_masks) {
+        P.base_masks.assign(c->n, 0u);
+        int rc = f2v_push_masks(c->rowptr.data(), c->colids.data(), c->n, batch, P.world, nullptr, 0, P.base_masks.data());
+        if (rc != F2V_OK) return rc;
+        HIPC(hipStreamSynchronize(c->stream));
+        if (!P.d_masks) HIPC(hipMalloc((void **)&P.d_masks, (size_t)c->n * sizeof(uint32_t)));
+        HIPC(hipMemcpy(P.d_masks, P.base_masks.data(), (size_t)c->n * sizeof(uint32_t), hipMemcpyHostToDevice));
+        P.patched_ids.clear();
+        P.mask_batch = batch;
+        P.mask_world = P.world;
+        P.pushed_per_epoch = 0;
+        for (uint32_t b0 = 0; b0 < c->n; b0 += batch) {
+            uint32_t lo, hi;
+            shard_of(b0, (uint32_t)std::min<uint64_t>((uint64_t)b0 + batch, c->n), P.rank, P.world, &lo, &hi);
+            for (uint32_t v = lo; v < hi; v++) P.pushed_per_epoch += (uint64_t)__builtin_popcount(P.base_masks[v]);
+        }
+    }
+    // patch list: [restore ids | restore values | set ids | set values]
+    std::vector<uint32_t> uniq(ids);
+    std::sort(uniq.begin(), uniq.end());
+    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+    const size_t nr = P.patched_ids.size(), ns = uniq.size();
+    if (nr + ns == 0) return F2V_OK;
+    std::vector<uint32_t> h(2 * (nr + ns));
+    for (size_t k = 0; k < nr; k++) { h[k] = P.patched_ids[k]; h[nr + k] = P.base_masks[P.patched_ids[k]]; }
+    const uint32_t everyone = (P.world >= 32 ? 0xFFFFFFFFu : ((1u << P.world) - 1u));
+    for (size_t k = 0; k < ns; k++) { h[2 * nr + k] = uniq[k]; h[2 * nr + ns + k] = everyone; }
+    HIPC(hipStreamSynchronize(c->stream));
+    if (h.size() > P.patch_cap) {
+        if (P.d_patch) (void)hipFree(P.d_patch);
+        P.d_patch = nullptr;
+        P.patch_cap = h.size() * 2;
+        HIPC(hipMalloc((void **)&P.d_patch, P.patch_cap * sizeof(uint32_t)));
+    }
+    HIPC(hipMemcpy(P.d_patch, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (nr) hipLaunchKernelGGL(mask_patch_kernel, dim3((uint32_t)((nr + 255) / 256)), dim3(256), 0, c->stream, P.d_masks, P.d_patch, P.d_patch + nr, (uint32_t)nr);
+    if (ns) hipLaunchKernelGGL(mask_patch_kernel, dim3((uint32_t)((ns + 255) / 256)), dim3(256), 0, c->stream, P.d_masks, P.d_patch + 2 * nr, P.d_patch + 2 * nr + ns, (uint32_t)ns);
+    HIPC(hipGetLastError());
+    P.patched_ids.swap(uniq);
+    return F2V_OK;
+}
+
+int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t ns, float lr, int bs_mode, double *seconds_out, bool sharded);
+
 }  // namespace
 
 extern "C" {
@@ -457,9 +605,9 @@ int f2v_create(const uint32_t *rowptr, const uint32_t *colids, uint32_t n, uint6
 int f2v_destroy(f2v_handle c) {
     if (!c) return F2V_OK;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)push_detach(c);
     void *ptrs[] = {c->d_rowptr, c->d_colids, c->d_walks, c->d_ids, c->d_X[0], c->d_X[1],
-                    c->d_partials, c->d_table, c->d_items, c->d_hubs};
+                    c->d_partials, c->d_table, c->d_items, c->d_hubs, c->push.flags, c->push.d_err, c->push.d_masks, c->push.d_patch};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -591,6 +739,11 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
         c->rows_in_flight = (int)value;
         return F2V_OK;
     }
+    if (!strcmp(name, "push_timeout_ms")) {
+        if (value < 1 || value > 600000) return fail(F2V_EINVAL, "push_timeout_ms must be 1..600000");
+        c->push.timeout_ms = value;
+        return F2V_OK;
+    }
     if (!strcmp(name, "waves_per_block")) {
         if (value != 1 && value != 2 && value != 4) return fail(F2V_EINVAL, "waves_per_block must be 1, 2 or 4");
         c->waves_per_block = (int)value;
@@ -608,6 +761,9 @@ int f2v_get_param(f2v_handle c, const char *name, int64_t *out) {
     if (!strcmp(name, "fast_rng")) { *out = c->fast_rng ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "use_graph")) { *out = c->use_graph ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "hub_chunk_auto")) { *out = c->chunk_auto ? 1 : 0; return F2V_OK; }
+    if (!strcmp(name, "push_timeout_ms")) { *out = c->push.timeout_ms; return F2V_OK; }
+    if (!strcmp(name, "push_world")) { *out = c->push.attached ? c->push.world : 0; return F2V_OK; }
+    if (!strcmp(name, "push_rank")) { *out = c->push.rank; return F2V_OK; }
     if (!strcmp(name, "dim")) { *out = c->D; return F2V_OK; }
     if (!strcmp(name, "n")) { *out = c->n; return F2V_OK; }
     if (!strcmp(name, "nnz")) { *out = (int64_t)c->nnz; return F2V_OK; }
@@ -807,6 +963,23 @@ int f2v_get_stats(f2v_handle c, f2v_stats *out) {
 int f2v_train(f2v_handle c, int option, uint32_t iters, uint32_t batch, uint32_t ns, float lr, int bs_mode,
               double *seconds_out) {
     if (!c) return fail(F2V_EINVAL, "null handle");
+    return train_impl(c, option, iters, batch, ns, lr, bs_mode, seconds_out, false);
+}
+
+int f2v_train_sharded(f2v_handle c, int option, uint32_t iters, uint32_t batch, uint32_t ns, float lr, int bs_mode,
+                      double *seconds_out) {
+    if (!c) return fail(F2V_EINVAL, "null handle");
+    if (!c->push.attached) return fail(F2V_ESTATE, "f2v_train_sharded: f2v_push_attach first");
+    return train_impl(c, option, iters, batch, ns, lr, bs_mode, seconds_out, true);
+}
+
+}  // extern "C"
+
+namespace {
+
+// f2v_train, and f2v_train_sharded when `sharded`: this rank computes its slice of every minibatch, pushes the new
+// rows to the peers that read them and passes the flag barrier before the next minibatch.
+int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t ns, float lr, int bs_mode, double *seconds_out, bool sharded) {
     const int math = math_of_option(option);
     if (!math) return fail(F2V_EINVAL, "f2v_train: option %d is outside 5..11", option);
     if (!c->have_x) return fail(F2V_ESTATE, "f2v_train: embeddings not initialised (f2v_init_embeddings)");
@@ -821,7 +994,11 @@ int f2v_train(f2v_handle c, int option, uint32_t iters, uint32_t batch, uint32_t
     const uint64_t stride = bs_mode ? (uint64_t)std::min(batch, n) + ns : ns;  // ids kept per minibatch
     const uint64_t per_epoch = (uint64_t)nb * stride;
     if (c->chunk_auto) {
-        const uint32_t ch = auto_chunk(c, batch);
+        // sharded: a rank's launch covers batch/world rows, and its longest serial stretch (one chunk) has to
+        // shrink with it or the step kernel stops getting shorter (measured on RMAT-20, B = 65536, 8 ranks: 87 us
+        // per minibatch with the whole batch's chunk, 32 us with the slice's).  The chunk is part of the summation
+        // order: results are bit-identical for any world size GIVEN the chunk ("hub_chunk" pins it).
+        const uint32_t ch = auto_chunk(c, sharded ? (batch + c->push.world - 1) / c->push.world : batch);
         if (ch != c->chunk) {
             if ((rc = flush_pending(c)) != F2V_OK) return rc;
             HIPC(hipStreamSynchronize(c->stream));
@@ -860,12 +1037,22 @@ int f2v_train(f2v_handle c, int option, uint32_t iters, uint32_t batch, uint32_t
         ids.assign(per_epoch, 0u);
     }
     c->stats = f2v_stats{};
+    // sharded: who reads which row is static when the neighbours are the CSR's and the run's sample ids are known
+    // up-front; otherwise (option 7's walks, -bs 1's per-row sample windows) every new row goes to every peer
+    const bool exchanging = sharded && c->push.world > 1;
+    const bool need_based = exchanging && math != 7 && !bs_mode && all_upfront;
+    const uint32_t *d_masks = nullptr;
+    if (need_based) {
+        if ((rc = prepare_masks(c, batch, ids)) != F2V_OK) return rc;
+        d_masks = c->push.d_masks;
+    }
+    if (sharded) c->push.rows_pushed = c->push.rows_allgather = 0;
     hipEvent_t ev0, ev1;
     HIPC(hipEventCreate(&ev0));
     HIPC(hipEventCreate(&ev1));
     HIPC(hipEventRecord(ev0, c->stream));
     std::vector<uint32_t> walks;
-    const bool graphed = c->use_graph && math != 7 && all_upfront && iters >= 2;
+    const bool graphed = c->use_graph && math != 7 && all_upfront && iters >= 2 && !sharded;
     if (graphed) {
         // hipGraph replay: an epoch's launch chain is identical every epoch except for (a) which of the two matrices
         // is read and which written -- they alternate, hence one graph per epoch parity -- and (b) the sample ids,
@@ -920,10 +1107,29 @@ int f2v_train(f2v_handle c, int option, uint32_t iters, uint32_t batch, uint32_t
         for (uint32_t b = 0; b < nb; b++) {
             const uint32_t lo = b * batch;
             const uint32_t hi = (uint32_t)std::min<uint64_t>((uint64_t)lo + batch, n);
-            if ((rc = launch_step(c, math, lo, hi, lo, hi, d_epoch_ids + (size_t)b * stride, ns, lr, bs_mode)) != F2V_OK) return rc;
+            uint32_t my_lo = lo, my_hi = hi;
+            if (sharded) shard_of(lo, hi, c->push.rank, c->push.world, &my_lo, &my_hi);
+            if ((rc = launch_step(c, math, lo, hi, my_lo, my_hi, d_epoch_ids + (size_t)b * stride, ns, lr, bs_mode)) != F2V_OK) return rc;
+            if (exchanging) {
+                if ((rc = launch_push(c, c->cur ^ 1, d_masks, my_lo, my_hi)) != F2V_OK) return rc;
+                if ((rc = launch_barrier(c)) != F2V_OK) return rc;
+                c->push.rows_allgather += (uint64_t)(my_hi - my_lo) * (c->push.world - 1);
+            }
         }
+        if (exchanging) c->push.rows_pushed += need_based ? c->push.pushed_per_epoch : (uint64_t)0;
     }
+    if (exchanging && !need_based) c->push.rows_pushed = c->push.rows_allgather;
     if ((rc = flush_pending(c)) != F2V_OK) return rc;
+    if (need_based && iters > 0) {
+        // replicas are complete only in the rows their rank reads: one full exchange makes them whole
+        for (uint32_t b = 0; b < nb; b++) {
+            const uint32_t lo = b * batch;
+            uint32_t my_lo, my_hi;
+            shard_of(lo, (uint32_t)std::min<uint64_t>((uint64_t)lo + batch, n), c->push.rank, c->push.world, &my_lo, &my_hi);
+            if ((rc = launch_push(c, c->cur, nullptr, my_lo, my_hi)) != F2V_OK) return rc;
+        }
+        if ((rc = launch_barrier(c)) != F2V_OK) return rc;
+    }
     HIPC(hipEventRecord(ev1, c->stream));
     HIPC(hipEventSynchronize(ev1));
     float ms = 0.f;
@@ -932,6 +1138,150 @@ int f2v_train(f2v_handle c, int option, uint32_t iters, uint32_t batch, uint32_t
     (void)hipEventDestroy(ev1);
     c->stats.device_seconds = ms * 1e-3;
     if (seconds_out) *seconds_out = ms * 1e-3;
+    if (exchanging) return check_push_err(c, "f2v_train_sharded");
+    return F2V_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int f2v_push_export(f2v_handle c, void *handles_out) {
+    if (!c || !handles_out) return fail(F2V_EINVAL, "f2v_push_export: null argument");
+    HIPC(hipSetDevice(c->device));
+    if (c->push.attached) return fail(F2V_ESTATE, "f2v_push_export: detach first");
+    int rc = flush_pending(c);
+    if (rc != F2V_OK) return rc;
+    HIPC(hipStreamSynchronize(c->stream));
+    // fresh, zeroed flags for every attachment: no peer can write them before it has seen this export
+    if (c->push.flags) (void)hipFree(c->push.flags);
+    c->push.flags = nullptr;
+    HIPC(hipExtMallocWithFlags((void **)&c->push.flags, 4096, hipDeviceMallocFinegrained));
+    HIPC(hipMemset(c->push.flags, 0, 4096));
+    if (!c->push.d_err) HIPC(hipMalloc((void **)&c->push.d_err, 64));
+    HIPC(hipMemset(c->push.d_err, 0, 64));
+    HIPC(hipDeviceSynchronize());
+    c->push.seq = 0;
+    PushExport e{};
+    for (int k = 0; k < 2; k++) HIPC(hipIpcGetMemHandle(&e.x[k], c->d_X[k]));
+    HIPC(hipIpcGetMemHandle(&e.flags, c->push.flags));
+    e.magic = kPushMagic;
+    e.n = c->n;
+    e.D = c->D;
+    e.cur = (uint32_t)c->cur;
+    memcpy(handles_out, &e, sizeof e);
+    c->push.exported = true;
+    return F2V_OK;
+}
+
+int f2v_push_attach(f2v_handle c, uint32_t rank, uint32_t world, const void *all_handles) {
+    if (!c || !all_handles) return fail(F2V_EINVAL, "f2v_push_attach: null argument");
+    if (world == 0 || world > (uint32_t)kMaxRanks || rank >= world) return fail(F2V_EINVAL, "f2v_push_attach: rank %u of %u (at most %d ranks)", rank, world, kMaxRanks);
+    if (!c->push.exported) return fail(F2V_ESTATE, "f2v_push_attach: f2v_push_export first");
+    if (c->push.attached) return fail(F2V_ESTATE, "f2v_push_attach: already attached");
+    HIPC(hipSetDevice(c->device));
+    const PushExport *all = static_cast<const PushExport *>(all_handles);
+    for (uint32_t r = 0; r < world; r++) {
+        PushExport e;
+        memcpy(&e, all + r, sizeof e);
+        if (e.magic != kPushMagic) return fail(F2V_EINVAL, "f2v_push_attach: export of rank %u is not an export", r);
+        if (e.n != c->n || e.D != c->D || e.cur != (uint32_t)c->cur)
+            return fail(F2V_ESTATE, "f2v_push_attach: rank %u holds a different engine state (n %u dim %u matrix %u; here %u %u %d)", r, e.n, e.D, e.cur, c->n, c->D, c->cur);
+    }
+    c->push.rank = rank;
+    c->push.world = world;
+    c->push.attached = true;  // from here on push_detach unmaps whatever got mapped
+    for (uint32_t r = 0; r < world; r++) {
+        if (r == rank) {
+            for (int k = 0; k < 2; k++) c->push.peer_X[k][r] = c->d_X[k];
+            c->push.peer_flags[r] = c->push.flags;
+            continue;
+        }
+        PushExport e;
+        memcpy(&e, all + r, sizeof e);
+        for (int k = 0; k < 2; k++) {
+            hipError_t he = hipIpcOpenMemHandle((void **)&c->push.peer_X[k][r], e.x[k], hipIpcMemLazyEnablePeerAccess);
+            if (he != hipSuccess) {
+                c->push.peer_X[k][r] = nullptr;
+                (void)push_detach(c);
+                return fail(F2V_ENODEV, "f2v_push_attach: cannot map the matrix of rank %u: %s", r, hipGetErrorString(he));
+            }
+        }
+        hipError_t he = hipIpcOpenMemHandle((void **)&c->push.peer_flags[r], e.flags, hipIpcMemLazyEnablePeerAccess);
+        if (he != hipSuccess) {
+            c->push.peer_flags[r] = nullptr;
+            (void)push_detach(c);
+            return fail(F2V_ENODEV, "f2v_push_attach: cannot map the flags of rank %u: %s", r, hipGetErrorString(he));
+        }
+    }
+    c->push.mask_batch = 0;  // masks depend on (rank, world)
+    c->push.exported = false;
+    return F2V_OK;
+}
+
+int f2v_test_push_attach_local(f2v_handle c, uint32_t rank, uint32_t world, const f2v_handle *all) {
+    if (!c || !all) return fail(F2V_EINVAL, "f2v_test_push_attach_local: null argument");
+    if (world == 0 || world > (uint32_t)kMaxRanks || rank >= world || all[rank] != c) return fail(F2V_EINVAL, "f2v_test_push_attach_local: rank %u of %u", rank, world);
+    if (!c->push.exported) return fail(F2V_ESTATE, "f2v_test_push_attach_local: f2v_push_export first (it creates the flags)");
+    if (c->push.attached) return fail(F2V_ESTATE, "f2v_test_push_attach_local: already attached");
+    for (uint32_t r = 0; r < world; r++) {
+        if (!all[r] || !all[r]->push.flags || all[r]->n != c->n || all[r]->D != c->D || all[r]->cur != c->cur || all[r]->device != c->device)
+            return fail(F2V_ESTATE, "f2v_test_push_attach_local: peer %u is not an exported engine of the same shape on the same device", r);
+        for (int k = 0; k < 2; k++) c->push.peer_X[k][r] = all[r]->d_X[k];
+        c->push.peer_flags[r] = all[r]->push.flags;
+    }
+    c->push.rank = rank;
+    c->push.world = world;
+    c->push.attached = c->push.local = true;
+    c->push.mask_batch = 0;
+    c->push.exported = false;
+    return F2V_OK;
+}
+
+int f2v_push_detach(f2v_handle c) {
+    if (!c) return fail(F2V_EINVAL, "null handle");
+    HIPC(hipSetDevice(c->device));
+    return push_detach(c);
+}
+
+int f2v_push_selftest(f2v_handle c) {
+    if (!c) return fail(F2V_EINVAL, "null handle");
+    if (!c->push.attached) return fail(F2V_ESTATE, "f2v_push_selftest: f2v_push_attach first");
+    HIPC(hipSetDevice(c->device));
+    int rc = flush_pending(c);
+    if (rc != F2V_OK) return rc;
+    const uint32_t W = c->push.world, me = c->push.rank, D = c->D;
+    const int which = c->cur ^ 1;  // the slack rows behind row N of the matrix no epoch is reading
+    // a pattern nobody could hold by accident: depends on the rank and on how many barriers have passed (the same
+    // number on every rank)
+    const unsigned long long nonce = c->push.seq;
+    auto value = [&](uint32_t r, uint32_t d) { return (float)(1 + r) * 1000.0f + (float)(nonce % 977) + (float)d / 1024.0f; };
+    std::vector<float> row(D);
+    for (uint32_t d = 0; d < D; d++) row[d] = value(me, d);
+    HIPC(hipMemcpyAsync(c->d_X[which] + (size_t)(c->n + me) * D, row.data(), D * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    if ((rc = launch_barrier(c)) != F2V_OK) return rc;  // nobody pushes before everybody has laid its pattern down
+    if ((rc = launch_push(c, which, nullptr, c->n + me, c->n + me + 1)) != F2V_OK) return rc;
+    if ((rc = launch_barrier(c)) != F2V_OK) return rc;
+    HIPC(hipStreamSynchronize(c->stream));
+    if ((rc = check_push_err(c, "f2v_push_selftest")) != F2V_OK) return rc;
+    std::vector<float> got((size_t)W * D);
+    HIPC(hipMemcpy(got.data(), c->d_X[which] + (size_t)c->n * D, got.size() * sizeof(float), hipMemcpyDeviceToHost));
+    bool ok = true;
+    for (uint32_t r = 0; r < W && ok; r++)
+        for (uint32_t d = 0; d < D; d++)
+            if (got[(size_t)r * D + d] != value(r, d)) { ok = false; break; }
+    if ((rc = launch_barrier(c)) != F2V_OK) return rc;  // nobody reuses the slack rows before everybody has checked
+    HIPC(hipStreamSynchronize(c->stream));
+    if ((rc = check_push_err(c, "f2v_push_selftest")) != F2V_OK) return rc;
+    if (!ok) return fail(F2V_ENODEV, "f2v_push_selftest: a peer's row did not arrive intact");
+    return F2V_OK;
+}
+
+int f2v_push_stats(f2v_handle c, uint64_t *rows_pushed_out, uint64_t *rows_allgather_out) {
+    if (!c) return fail(F2V_EINVAL, "null handle");
+    if (rows_pushed_out) *rows_pushed_out = c->push.rows_pushed;
+    if (rows_allgather_out) *rows_allgather_out = c->push.rows_allgather;
     return F2V_OK;
 }
 

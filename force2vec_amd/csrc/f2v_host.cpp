@@ -429,4 +429,56 @@ int f2v_output_name(const char *input, const char *outdir, int option, int bs_mo
     return F2V_OK;
 }
 
+// Who reads which row in the sharded run (include/f2v.h: the push exchange).  One pass over the CSR: the owner of
+// row u reads every neighbour of u; threads take row ranges and OR their rank's bit in atomically.
+int f2v_push_masks(const uint32_t *rowptr, const uint32_t *colids, uint32_t n, uint32_t batch, uint32_t world,
+                   const uint32_t *sample_ids, uint64_t n_ids, uint32_t *masks) {
+    if (!rowptr || !masks || (!colids && rowptr[n]) || (!sample_ids && n_ids)) return fail(F2V_EINVAL, "f2v_push_masks: null argument");
+    if (batch == 0 || world == 0 || world > 32) return fail(F2V_EINVAL, "f2v_push_masks: batch %u / world %u", batch, world);
+    auto owner = [=](uint32_t u) -> uint32_t {
+        const uint32_t lo = (u / batch) * batch;
+        const uint32_t hi = (uint32_t)std::min<uint64_t>((uint64_t)lo + batch, n);
+        const uint32_t per = (hi - lo + world - 1) / world;
+        return (u - lo) / per;
+    };
+    memset(masks, 0, (size_t)n * sizeof(uint32_t));
+    unsigned T = std::thread::hardware_concurrency();
+    if (const char *e = getenv("F2V_IO_THREADS")) T = (unsigned)atoi(e);
+    T = std::max(1u, std::min(T, 64u));
+    if (rowptr[n] < (1u << 20)) T = 1;
+    auto work = [&](uint32_t r0, uint32_t r1) {
+        for (uint32_t u = r0; u < r1; u++) {
+            const uint32_t bit = 1u << owner(u);
+            for (uint32_t k = rowptr[u]; k < rowptr[u + 1]; k++) {
+                uint32_t *m = masks + colids[k];
+                if (!(__atomic_load_n(m, __ATOMIC_RELAXED) & bit)) __atomic_fetch_or(m, bit, __ATOMIC_RELAXED);
+            }
+        }
+    };
+    if (T == 1) {
+        work(0, n);
+    } else {
+        std::vector<std::thread> th;
+        const uint64_t nnz = rowptr[n];
+        uint32_t r0 = 0;
+        for (unsigned t = 0; t < T; t++) {  // equal shares of the nonzeros
+            const uint64_t target = nnz * (t + 1) / T;
+            uint32_t r1 = (t == T - 1) ? n : (uint32_t)(std::upper_bound(rowptr, rowptr + n + 1, (uint32_t)target) - rowptr - 1);
+            r1 = std::max(r1, r0);
+            if (t == T - 1) r1 = n;
+            th.emplace_back(work, r0, r1);
+            r0 = r1;
+        }
+        for (auto &y : th) y.join();
+    }
+    const uint32_t everyone = world >= 32 ? 0xFFFFFFFFu : ((1u << world) - 1u);
+    for (uint64_t k = 0; k < n_ids; k++) {
+        if (sample_ids[k] >= n) return fail(F2V_EINVAL, "f2v_push_masks: sample id %u is not a vertex", sample_ids[k]);
+        masks[sample_ids[k]] = everyone;
+    }
+    for (uint32_t v = 0; v < n; v++) masks[v] &= ~(1u << owner(v));  // the owner has the row already
+    return F2V_OK;
+}
+
+
 }  // extern "C"

@@ -612,6 +612,112 @@ __global__ __launch_bounds__(256) void commit_kernel(float *X, const float *Xn, 
     }
 }
 
+// ---- multi-GPU: push exchange over xGMI (include/f2v.h) ------------------------------------------------
+// Every rank holds both matrices of every peer mapped into its address space (HIP IPC).  After a minibatch's step
+// kernels a rank copies each of its new rows into the same row of the second matrix of every peer whose bit is set
+// in the row's reader mask: one wavefront per row, one coalesced row load (the row was written a moment ago: L2 /
+// MALL), one coalesced row store per reading peer.  The stores are posted writes on the direct xGMI link to that
+// peer, so all 7 links of a GPU carry traffic at once and nothing waits for a reply.  The stores are written
+// through at system scope and every wave waits for its acknowledgements: when the kernel has finished, its rows
+// are in the peers' memory.  (A release fence per wave instead -- buffer_wbl2 -- walks the whole L2 each time.)
+constexpr int kMaxRanks = 8;
+
+struct PushArgs {
+    const float *src;         // local matrix that holds the new rows
+    float *peer[kMaxRanks];   // that matrix on every rank (peer[self] is not written)
+    const uint32_t *masks;    // per vertex: bit r = rank r reads the row; nullptr = every rank does
+    uint32_t row_lo, rows;    // this rank's rows of the minibatch
+    uint32_t D, self, world;
+};
+
+// A row store that is written through to the peer's memory: relaxed system-scope atomic stores carry the sc0 sc1
+// bits, so the data does not linger in this GPU's L2 and no cache write-back is needed afterwards.
+template <int VEC, bool EXACT>
+__device__ __forceinline__ void store_row_system(float *dst, uint32_t lane, uint32_t D, const float (&in)[VEC]) {
+    if constexpr (VEC >= 2) {
+        if (EXACT || D % VEC == 0) {
+            if (EXACT || lane * VEC < D) {
+                unsigned long long *q = reinterpret_cast<unsigned long long *>(dst + lane * VEC);
+#pragma unroll
+                for (int v = 0; v < VEC; v += 2) {
+                    const unsigned long long bits = (unsigned long long)__builtin_bit_cast(uint32_t, in[v]) |
+                                                    ((unsigned long long)__builtin_bit_cast(uint32_t, in[v + 1]) << 32);
+                    __hip_atomic_store(q + v / 2, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        const uint32_t d = lane * VEC + v;
+        if (d < D) __hip_atomic_store(reinterpret_cast<uint32_t *>(dst + d), __builtin_bit_cast(uint32_t, in[v]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+template <int VEC, bool EXACT>
+__global__ __launch_bounds__(256) void push_rows_kernel(const PushArgs p) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wpb = blockDim.x >> 6;
+    const uint32_t total = gridDim.x * wpb;
+    const uint32_t others = ((p.world >= 32u ? 0xFFFFFFFFu : ((1u << p.world) - 1u))) & ~(1u << p.self);
+    for (uint32_t r = blockIdx.x * wpb + (threadIdx.x >> 6); r < p.rows; r += total) {
+        const uint32_t row = p.row_lo + r;
+        const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)((p.masks ? p.masks[row] : others) & others));
+        if (!m) continue;
+        float t[VEC];
+        load_row<VEC, EXACT>(p.src + (size_t)row * p.D, lane, p.D, t);
+#pragma unroll
+        for (int q = 0; q < kMaxRanks; ++q) {
+            if (m & (1u << q)) store_row_system<VEC, EXACT>(p.peer[q] + (size_t)row * p.D, lane, p.D, t);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);  // this wave's stores have been acknowledged by the peers' memory before it ends
+}
+
+// Flag barrier between minibatches, one 64-lane workgroup: lane r tells rank r "I have finished step `seq`" (a
+// system-scope release store into r's flag array, which lives in fine-grained memory and is mapped like the
+// matrices) and waits until rank r has told us the same.  The kernel runs on the engine's stream behind the push
+// kernel, so "finished" covers this rank's pushes; the next minibatch's step kernel runs behind it, so it starts only
+// when every peer's pushes have landed here.  Every wait is bounded by `timeout_ticks` of the 100 MHz wall clock: a
+// missing peer sets *err and the grid drains.
+struct BarrierArgs {
+    unsigned long long *flags;                  // local: flags[r] = last step rank r has announced
+    unsigned long long *peer_flags[kMaxRanks];  // the flag array of every rank
+    uint32_t *err;
+    unsigned long long seq, timeout_ticks;
+    uint32_t self, world;
+};
+
+__global__ __launch_bounds__(64) void xgmi_barrier_kernel(const BarrierArgs b) {
+    const uint32_t r = threadIdx.x;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __builtin_amdgcn_s_waitcnt(0);  // the write-back above has completed before any flag leaves
+    if (r < b.world && r != b.self) {
+        unsigned long long *theirs = b.peer_flags[0];
+#pragma unroll
+        for (int q = 1; q < kMaxRanks; ++q)
+            if ((uint32_t)q == r) theirs = b.peer_flags[q];
+        __hip_atomic_store(theirs + b.self, b.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long t0 = wall_clock64();
+        // relaxed system-scope loads go to memory every time without invalidating this XCD's L2 on every poll
+        while (__hip_atomic_load(b.flags + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < b.seq) {
+            __builtin_amdgcn_s_sleep(4);
+            if (wall_clock64() - t0 > b.timeout_ticks) {
+                __hip_atomic_store(b.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // once: what the peers pushed is read from memory from here on
+}
+
+// masks[idx[k]] = val[k] in order of k is not needed: indices are distinct within one patch list
+__global__ void mask_patch_kernel(uint32_t *masks, const uint32_t *idx, const uint32_t *val, uint32_t count) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < count) masks[idx[k]] = val[k];
+}
+
 // ---- non-parity fast mode: counter-based RNG on the device ---------------------------
 // The reference's libc rand() stream is inherently serial (and, for the option-7 walks, its consumption is
 // data dependent), so the parity path draws it on the host.  For very large N that costs seconds per run

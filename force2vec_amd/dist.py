@@ -8,10 +8,12 @@ and ONE exchange per minibatch -- an all-gather of the staged new rows, B x D fp
 makes every replica identical again.  Results are bit-identical to the single-GPU run for any
 world size.  Every rank draws the same rand() stream on its host.
 
-Three interchangeable exchanges, all bit-identical in result: NcclStageComm (default: an in-place RCCL all-gather
-on those rows of the second matrix, zero-copy on the engine's own HIP stream), HostStageComm (the same through
-host memory: gloo, tests, and NcclStageComm's insurance path) and NeedExchange (per-destination all-to-all-v:
-a rank receives only the rows it reads)."""
+Four interchangeable exchanges, all bit-identical in result: PushExchange (the engine's own: new rows are stored
+straight into the reading peers' matrices over xGMI by a HIP kernel, a device-side flag barrier separates
+minibatches, the whole epoch loop runs inside libf2v -- torch.distributed only carries the IPC handles once),
+NcclStageComm (an in-place RCCL all-gather on those rows of the second matrix, zero-copy on the engine's own HIP
+stream), HostStageComm (the same through host memory: gloo, tests, and NcclStageComm's insurance path) and
+NeedExchange (per-destination all-to-all-v: a rank receives only the rows it reads)."""
 import numpy as np
 
 
@@ -273,6 +275,60 @@ class NeedExchange:
             engine.set_embeddings(X)
 
 
+class PushExchange:
+    """The engine's push exchange (include/f2v.h "multi-GPU: the push exchange over xGMI").
+
+    attach(): every rank exports the HIP IPC handles of its two matrices and its flag array, the process group
+    gathers them (the only use of torch.distributed on this path), every rank maps its peers and the ranks run the
+    self-test together.  Raises if any rank failed -- on every rank, so that all of them fall back together."""
+
+    def __init__(self, dist, rank, world, group=None):
+        self.dist, self.rank, self.world, self.group = dist, rank, world, group
+        self.attached = False
+
+    def _all_ok(self, ok):
+        flags = [None] * self.world
+        self.dist.all_gather_object(flags, bool(ok), group=self.group)
+        return all(flags)
+
+    def attach(self, engine, selftest=True):
+        err = None
+        try:
+            mine = engine.push_export()
+        except Exception as ex:  # noqa: BLE001 -- reported after the ranks have agreed
+            err, mine = ex, b""
+        exports = [None] * self.world
+        self.dist.all_gather_object(exports, mine, group=self.group)
+        if all(len(e) == len(exports[0]) and len(e) > 0 for e in exports):
+            try:
+                engine.push_attach(self.rank, self.world, exports)
+            except Exception as ex:  # noqa: BLE001
+                err = ex
+        elif err is None:
+            err = RuntimeError("a peer could not export its IPC handles")
+        ok = self._all_ok(err is None)  # also: nobody launches a barrier kernel before everybody has mapped everybody
+        if ok and selftest:
+            try:
+                engine.push_selftest()
+            except Exception as ex:  # noqa: BLE001
+                err = ex
+            ok = self._all_ok(err is None)
+        if not ok:
+            try:
+                engine.push_detach()
+            except Exception:  # noqa: BLE001
+                pass
+            raise RuntimeError("push exchange unavailable on rank %d: %r" % (self.rank, err))
+        self.attached = True
+
+    def detach(self, engine):
+        if self.attached:
+            engine.synchronize()
+            self._all_ok(True)  # no peer unmaps while another still pushes
+            engine.push_detach()
+            self.attached = False
+
+
 class ShardedTrainer:
     """AlgoForce2Vec* over `world` engines: same epochs, minibatches and rand() order as f2v_train."""
 
@@ -283,13 +339,19 @@ class ShardedTrainer:
 
     def train(self, option, iters, batch, ns=5, lr=0.02, bs_mode=0):
         e = self.engine
+        if isinstance(self.comm, PushExchange):
+            if not self.comm.attached:
+                self.comm.attach(e)
+            return e.train_sharded(option, iters, batch, ns, lr, bs_mode)  # the whole loop runs inside libf2v
         n = e.n
         math = math_of_option(option)
         if math == 7 and bs_mode:
             raise ValueError("option 7 has no -bs 1 variant")
         nb = -(-n // batch)
         if e.get_param("hub_chunk_auto"):
-            e.set_param("hub_chunk_for_batch", batch)  # same chunk as the single-GPU f2v_train, whatever the world size
+            # the chunk follows the rows ONE launch covers (a slice), exactly as f2v_train_sharded picks it: every
+            # exchange then gives the same bits; "hub_chunk" pins it for bits that do not depend on the world size
+            e.set_param("hub_chunk_for_batch", -(-batch // self.world))
         if self.need_based and math == 7:
             raise ValueError("the per-destination exchange needs static neighbour lists: options 5/6 only")
         ndraw = ns * batch if bs_mode else ns

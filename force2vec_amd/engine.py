@@ -89,6 +89,35 @@ class Engine:
         check(self._L.f2v_train(self._h, option, iters, batch, ns, lr, bs_mode, C.byref(sec)))
         return sec.value
 
+    # -- multi-GPU push exchange over xGMI (include/f2v.h) ----------------------------------------
+    def push_export(self):
+        """-> bytes: this rank's IPC handles (gather them from all ranks, then push_attach)."""
+        buf = C.create_string_buffer(_lib.PUSH_EXPORT_BYTES)
+        check(self._L.f2v_push_export(self._h, buf))
+        return buf.raw
+
+    def push_attach(self, rank, world, exports):
+        blob = b"".join(exports)
+        assert len(blob) == world * _lib.PUSH_EXPORT_BYTES
+        check(self._L.f2v_push_attach(self._h, rank, world, C.c_char_p(blob)))
+
+    def push_selftest(self):
+        check(self._L.f2v_push_selftest(self._h))
+
+    def push_detach(self):
+        check(self._L.f2v_push_detach(self._h))
+
+    def push_stats(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        check(self._L.f2v_push_stats(self._h, C.byref(a), C.byref(b)))
+        return {"rows_pushed": a.value, "rows_allgather": b.value}
+
+    def train_sharded(self, option, iters, batch, ns=5, lr=0.02, bs_mode=0):
+        """f2v_train over the attached ranks -> device seconds of the epoch loop (exchange included)."""
+        sec = C.c_double()
+        check(self._L.f2v_train_sharded(self._h, option, iters, batch, ns, lr, bs_mode, C.byref(sec)))
+        return sec.value
+
     def minibatch_step(self, option, batch_lo, batch_hi, sample_ids, ns, lr, bs_mode=0, row_lo=None, row_hi=None):
         ids = np.ascontiguousarray(sample_ids, dtype=np.uint32)
         check(self._L.f2v_minibatch_step(self._h, option, batch_lo, batch_hi,
@@ -165,6 +194,16 @@ class Engine:
         s = _lib.Stats()
         check(self._L.f2v_get_stats(self._h, C.byref(s)))
         return {k: getattr(s, k) for k, _ in s._fields_}
+
+
+def push_masks(rowptr, colids, batch, world, sample_ids=()):
+    """f2v_push_masks (host only): uint32[n], bit r = rank r reads the row without owning it."""
+    rp = np.ascontiguousarray(rowptr, dtype=np.uint32)
+    ci = np.ascontiguousarray(colids, dtype=np.uint32)
+    ids = np.ascontiguousarray(sample_ids, dtype=np.uint32)
+    out = np.zeros(len(rp) - 1, dtype=np.uint32)
+    check(_lib.lib().f2v_push_masks(_u32(rp), _u32(ci), len(rp) - 1, batch, world, _u32(ids), len(ids), _u32(out)))
+    return out
 
 
 def write_embd(path, X):

@@ -127,6 +127,43 @@ int f2v_embeddings_device_ptr(f2v_handle h, uint64_t *devptr_out);
 int f2v_stream(f2v_handle h, uint64_t *stream_out);
 int f2v_synchronize(f2v_handle h);
 
+/* ---- multi-GPU: the push exchange over xGMI -----------------------------------------------
+ * One process per GPU, the graph and both matrices replicated, rank r computes the r-th contiguous slice
+ * of every minibatch (north_star's "1-D vertex partition ... each minibatch"; the reference has no
+ * multi-device path).  What crosses GPUs is the NEW ROWS of a minibatch (forces only ever update the source
+ * row): after its step kernel a rank's push kernel stores each new row straight into the second matrix of
+ * every peer that READS that row -- the peers' matrices are mapped through HIP IPC, the stores travel
+ * over the direct xGMI link to that peer -- and a device-side flag barrier (one small kernel, no host
+ * round trip, no collective) separates minibatches.  Who reads a row is static for options 5/6: the ranks
+ * owning a CSR neighbour of it, plus everyone for a vertex some minibatch samples (f2v_push_masks).
+ * Results are bit-identical to the single-GPU f2v_train for any world size.
+ *
+ *   f2v_push_export   this rank's F2V_PUSH_EXPORT_BYTES bytes: IPC handles of both matrices and the flags, n, dim;
+ *                     the host gathers them from all ranks with whatever it has (torch.distributed, MPI, a file)
+ *   f2v_push_attach   map the peers (all_handles = world exports, in rank order); world <= F2V_PUSH_MAX_RANKS
+ *   f2v_push_selftest every rank writes a pattern into every peer's slack rows, barrier, verifies what it
+ *                     received: F2V_OK only if IPC mapping, remote stores and the flag barrier all work
+ *   f2v_train_sharded f2v_train over the attached ranks (every rank calls it with the same arguments after
+ *                     the same f2v_srand / f2v_init_embeddings); on return every replica is complete
+ *   f2v_push_detach   unmap the peers (also done by f2v_destroy)
+ * "push_timeout_ms" (f2v_set_param, default 20000) bounds every wait of the flag barrier: a missing peer
+ * makes the calls fail with F2V_ESTATE instead of hanging the GPU. */
+#define F2V_PUSH_MAX_RANKS 8
+#define F2V_PUSH_EXPORT_BYTES 256
+int f2v_push_export(f2v_handle h, void *handles_out);
+int f2v_push_attach(f2v_handle h, uint32_t rank, uint32_t world, const void *all_handles);
+int f2v_push_selftest(f2v_handle h);
+int f2v_push_detach(f2v_handle h);
+int f2v_train_sharded(f2v_handle h, int option, uint32_t iters, uint32_t batch, uint32_t ns, float lr, int bs_mode,
+                      double *seconds_out);
+/* Host-only: masks_out[v] = bit r set when rank r READS row v without owning it -- v is a CSR neighbour of a
+ * row in one of r's slices (slice r of minibatch [lo,hi) = rows lo + r*ceil((hi-lo)/world) ...), or one of
+ * `sample_ids` (read by every row of a minibatch, hence by every rank). */
+int f2v_push_masks(const uint32_t *rowptr, const uint32_t *colids, uint32_t n, uint32_t batch, uint32_t world,
+                   const uint32_t *sample_ids, uint64_t n_ids, uint32_t *masks_out);
+/* Rows pushed to peers / rows a full all-gather would have sent (per peer copies), since the last f2v_train_sharded began. */
+int f2v_push_stats(f2v_handle h, uint64_t *rows_pushed_out, uint64_t *rows_allgather_out);
+
 /* Statistics of the last f2v_train: launches of the step kernel, rows and nonzeros they
  * processed, algorithmic bytes (SURVEY 8d formula), device seconds. */
 typedef struct {
@@ -182,6 +219,9 @@ int f2v_sm_table(float *table_out /* 2048 */);
 /* ---- self-test hooks (used by tests/ only) ---------------------------------------------- */
 /* Runs the wavefront tree reduction on `rows` rows of `width` (<=512) floats; out[r] = sum. */
 int f2v_test_wave_reduce(int device, const float *in, uint32_t rows, uint32_t width, float *out);
+/* The push exchange between engines of ONE process on one device (direct pointers instead of HIP IPC; every
+ * engine is driven by its own host thread): runs the push kernels, masks and flag barriers under a profiler. */
+int f2v_test_push_attach_local(f2v_handle h, uint32_t rank, uint32_t world, const f2v_handle *all);
 /* PMC calibration: `reps` launches that each gather `rows` distinct 512-byte rows exactly once with
  * the step kernel's access pattern (known HBM read volume rows*516 bytes per launch). */
 int f2v_test_gather_calibration(int device, uint32_t rows, uint32_t reps);

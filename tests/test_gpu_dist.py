@@ -43,7 +43,12 @@ def _gloo_worker(rank, world, port, case, outdir, exchange="allgather"):
     eng = F.Engine(rp, ci, dim, device=0)
     eng.srand(1)
     eng.init_embeddings(0 if option in (5, 8, 11) else 1)
-    if exchange == "allgather":
+    if exchange == "push":
+        # the engine's own exchange: peers' matrices mapped through HIP IPC (here: other processes on the same GPU),
+        # rows pushed by a HIP kernel, device-side flag barrier; gloo only carries the handles
+        comm = fdist.PushExchange(dist, rank, world)
+        eng.set_param("push_timeout_ms", 8000)
+    elif exchange == "allgather":
         comm = fdist.HostStageComm(dist, rank, world)
     elif exchange == "need":
         comm = fdist.NeedExchange(dist, rank, world, backend="host")
@@ -60,11 +65,121 @@ def _gloo_worker(rank, world, port, case, outdir, exchange="allgather"):
         import torch
         torch.cuda.set_device(0)
         comm = fdist.NeedExchange(dist, rank, world, device=0, backend="device")
-    fdist.ShardedTrainer(eng, rank, world, comm).train(option, iters, batch, 5, 0.02, bs)
+    tr = fdist.ShardedTrainer(eng, rank, world, comm)
+    tr.train(option, iters, batch, 5, 0.02, bs)
+    if exchange == "push":
+        # a second run on the same attachment continues where the first stopped, exactly like two f2v_train calls
+        tr.train(option, 1, batch, 5, 0.02, bs)
+        st = eng.push_stats()
+        assert 0 < st["rows_pushed"] <= st["rows_allgather"]
     np.save(os.path.join(outdir, "r%d.npy" % rank), eng.get_embeddings())
+    if exchange == "push":
+        comm.detach(eng)
     eng.close()
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _single_twice(case):
+    import force2vec_amd as F
+    graph, option, iters, batch, dim, bs = case
+    rp, ci = F.read_mtx(golden_graph_path(graph))
+    eng = F.Engine(rp, ci, dim, device=0)
+    eng.srand(1)
+    eng.init_embeddings(0 if option in (5, 8, 11) else 1)
+    eng.train(option, iters, batch, 5, 0.02, bs)
+    eng.train(option, 1, batch, 5, 0.02, bs)
+    X = eng.get_embeddings()
+    eng.close()
+    return X
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("case", [("cora.mtx", 5, 3, 256, 128, 0), ("cora.mtx", 6, 2, 300, 64, 0), ("pubmed.mtx", 5, 2, 4096, 128, 0),
+                                  ("karate.mtx", 7, 3, 16, 64, 0), ("cora.mtx", 5, 2, 300, 100, 1), ("citeseer.mtx", 11, 2, 1000, 32, 0)])
+def test_push_exchange_between_processes_sharing_the_gpu(case, world, tmp_path):
+    """f2v_train_sharded: every rank maps its peers' matrices and flags through HIP IPC, pushes its new rows into
+    the peers that read them and passes the device-side flag barrier -- here between processes on ONE card (the
+    peer mappings then alias memory of the same GPU; IPC, masks, push kernel, barrier protocol and the final
+    completion pass are the code that runs across xGMI).  Bit-identical to the single-engine run on every rank."""
+    import torch.multiprocessing as mp
+    if case[0] == "pubmed.mtx" and world == 3:
+        pytest.skip("covered by world 2")
+    mp.spawn(_gloo_worker, args=(world, _free_port(), case, str(tmp_path), "push"), nprocs=world, join=True)
+    want = _single_twice(case)
+    for r in range(world):
+        assert np.array_equal(np.load(str(tmp_path / ("r%d.npy" % r))), want)
+
+
+def _rmat_push_worker(rank, world, port, outdir):
+    import torch.distributed as dist
+    import force2vec_amd as F
+    from force2vec_amd import dist as fdist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    rp, ci = F.rmat_csr(14, 16, 3)
+    eng = F.Engine(rp, ci, 128, device=0)
+    eng.srand(1)
+    eng.init_embeddings(0)
+    comm = fdist.PushExchange(dist, rank, world)
+    fdist.ShardedTrainer(eng, rank, world, comm).train(5, 3, 16384, 5, 0.02, 0)
+    np.save(os.path.join(outdir, "r%d.npy" % rank), eng.get_embeddings())
+    open(os.path.join(outdir, "chunk%d.txt" % rank), "w").write(str(eng.get_param("hub_chunk")))
+    comm.detach(eng)
+    eng.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_push_exchange_hub_chunk_follows_the_slice(tmp_path):
+    """A rank's launch covers batch/world rows, so the automatic hub chunk is chosen for the slice (a whole batch's
+    chunk would keep the step kernel as long as on one GPU).  The chunk is part of the summation order: the sharded
+    run equals the single engine run with THAT chunk bit for bit."""
+    import torch.multiprocessing as mp
+    import force2vec_amd as F
+    mp.spawn(_rmat_push_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    chunk = int(open(str(tmp_path / "chunk0.txt")).read())
+    rp, ci = F.rmat_csr(14, 16, 3)
+    eng = F.Engine(rp, ci, 128, device=0)
+    eng.set_param("hub_chunk_for_batch", 16384)
+    assert eng.get_param("hub_chunk") > chunk  # the case really exercises a slice-sized chunk
+    eng.set_param("hub_chunk", chunk)
+    eng.srand(1)
+    eng.init_embeddings(0)
+    eng.train(5, 3, 16384, 5, 0.02, 0)
+    want = eng.get_embeddings()
+    eng.close()
+    for r in range(2):
+        assert np.array_equal(np.load(str(tmp_path / ("r%d.npy" % r))), want)
+
+
+def _push_timeout_worker(rank, world, port, outdir):
+    import torch.distributed as dist
+    import force2vec_amd as F
+    from force2vec_amd import dist as fdist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    rp, ci = F.read_mtx(golden_graph_path("karate.mtx"))
+    eng = F.Engine(rp, ci, 64, device=0)
+    eng.srand(1)
+    eng.init_embeddings(0)
+    eng.set_param("push_timeout_ms", 300)
+    comm = fdist.PushExchange(dist, rank, world)
+    comm.attach(eng)
+    msg = "ok"
+    if rank == 0:  # rank 1 never trains: rank 0's first barrier must give up, not hang the GPU
+        try:
+            eng.train_sharded(5, 1, 16, 5, 0.02, 0)
+        except F.F2VError as ex:
+            msg = str(ex)
+    open(os.path.join(outdir, "r%d.txt" % rank), "w").write(msg)
+    dist.barrier()
+    eng.close()
+    dist.destroy_process_group()
+
+
+def test_push_barrier_times_out_instead_of_hanging(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_push_timeout_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert "did not reach the xGMI barrier" in open(str(tmp_path / "r0.txt")).read()
 
 
 @pytest.mark.parametrize("mode", ["need", "need_device", "nccl_refused"])

@@ -195,3 +195,36 @@ def test_parallel_init_equals_the_serial_rand_stream():
             assert np.array_equal(out, want), (kind, count)
             assert L.f2v_rng_next(g) == o.rand()
             L.f2v_rng_destroy(g)
+
+
+def test_push_masks_name_exactly_the_ranks_that_read_a_row():
+    """f2v_push_masks against a brute-force restatement: rank r reads v iff v is a CSR neighbour of a row in one of
+    r's minibatch slices, or v is sampled; the owner's own bit is never set."""
+    from force2vec_amd.engine import push_masks
+    from force2vec_amd.graph import rmat_csr
+    from force2vec_amd.dist import shard_bounds
+    rp, ci = rmat_csr(11, 8, 3)
+    n = len(rp) - 1
+    for batch, world in [(256, 2), (300, 3), (4096, 8), (100, 5)]:
+        samples = np.array([1, 7, n - 1, 7], dtype=np.uint32)
+        got = push_masks(rp, ci, batch, world, samples)
+        owner = np.zeros(n, dtype=np.int64)
+        for lo in range(0, n, batch):
+            hi = min(lo + batch, n)
+            for r in range(world):
+                _, a, b = shard_bounds(lo, hi, r, world)
+                owner[a:b] = r
+        want = np.zeros(n, dtype=np.uint32)
+        for u in range(n):
+            want[ci[rp[u]:rp[u + 1]]] |= np.uint32(1 << owner[u])
+        want[samples] = (1 << world) - 1
+        want &= ~(np.uint32(1) << owner.astype(np.uint32))
+        assert np.array_equal(got, want), (batch, world)
+    # the threaded path (>= 2^20 nonzeros) agrees with the serial one
+    rp, ci = rmat_csr(16, 16, 5)
+    os.environ["F2V_IO_THREADS"] = "1"
+    a = push_masks(rp, ci, 8192, 8)
+    os.environ["F2V_IO_THREADS"] = "7"
+    b = push_masks(rp, ci, 8192, 8)
+    del os.environ["F2V_IO_THREADS"]
+    assert np.array_equal(a, b) and a.any()
