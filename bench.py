@@ -138,11 +138,15 @@ def main():
     ap.add_argument("--exchange", choices=["push", "allgather", "need"], default="push",
                     help="N>1: push = the engine's own xGMI exchange (rows stored into the reading peers' HBM by a HIP kernel); "
                          "allgather = RCCL all-gather of every minibatch's new rows; need = RCCL all-to-all-v of only the rows each rank reads")
+    ap.add_argument("--push-fused", choices=["auto", "1", "0"], default="auto",
+                    help="push exchange: rows pushed by the step kernels themselves (1), by a kernel behind them (0), or whichever "
+                         "is faster on this machine over a few untimed epochs (auto)")
     ap.add_argument("--no-verify", action="store_true", help="N>1: skip the bit-for-bit check of every replica against a single-GPU run")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: self-test of the N>1 plumbing on a one-GPU box (all ranks on device 0, exchange through the host)")
     ap.add_argument("--force-dist", action="store_true", help="drive even a single rank through the multi-GPU path (RCCL group of 1): self-test")
-    ap.add_argument("--extra-batches", type=str, default="256,4096,16384", help="comma list of further batch sizes to time (reported under 'extra')")
+    ap.add_argument("--extra-batches", type=str, default="256,4096,16384,262144", help="N=1: comma list of further batch sizes to time (reported under 'extra')")
+    ap.add_argument("--dist-extra-batches", type=str, default="262144", help="N>1: the same for the sharded run (fewer, larger exchanges)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -172,10 +176,17 @@ def main():
             local_rank = 0
             dist.init_process_group("gloo")
         else:
+            if torch.cuda.device_count() <= local_rank:
+                local_rank = 0  # the launcher gave every rank its own single visible device
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            host_group = dist.new_group(backend="gloo") if world > 1 else None  # insurance path of NcclStageComm
+            host_group = dist.new_group(backend="gloo") if world > 1 else None  # handle exchange of the push path, insurance path of NcclStageComm
 
+    if use_dist and world > 1:
+        # one rank generates (or finds) the cached graph, the others read the cache
+        if rank == 0:
+            load_graph(args.scale, 16, 1)
+        dist.barrier(group=host_group) if host_group is not None else dist.barrier()
     rowptr, colids = load_graph(args.scale, 16, 1)
     n, nnz = len(rowptr) - 1, len(colids)
     eng = F.Engine(rowptr, colids, args.dim, device=local_rank)
@@ -220,8 +231,11 @@ def main():
         state["comm"] = comm
         return comm
 
+    schedule = []  # every (epochs, batch) trained so far: the verification replays it on one engine
+
     def run_epochs(k, batch):
         """-> per-rank statistics of these k epochs (launches, algorithmic bytes, device seconds where known)."""
+        schedule.append((k, batch))
         if not use_dist:
             eng.train(args.option, k, batch, 5, 0.02, 0)
             return eng.stats()
@@ -243,12 +257,33 @@ def main():
         t0 = time.perf_counter()
         st = run_epochs(k, batch)
         barrier()
-        dt = time.perf_counter() - t0
-        if use_dist:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+        dt = max_over_ranks(time.perf_counter() - t0)
         return dt, st
+
+    def max_over_ranks(x):
+        if not use_dist:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def tune_push():
+        """Untimed: which of the two push variants is faster here?  Every rank sees the same (max-over-ranks) times."""
+        if args.push_fused != "auto":
+            eng.set_param("push_fused", int(args.push_fused))
+            return
+        run_epochs(1, args.batch)  # launch plans and reader masks exist from here on
+        took = {}
+        for fused in (1, 0):
+            eng.set_param("push_fused", fused)
+            barrier()
+            t0 = time.perf_counter()
+            run_epochs(3, args.batch)
+            barrier()
+            took[fused] = max_over_ranks(time.perf_counter() - t0) / 3
+        best = 1 if took[1] <= took[0] else 0
+        eng.set_param("push_fused", best)
+        state["tuned"] = {"push_fused": best, "ms_per_epoch_fused": took[1] * 1e3, "ms_per_epoch_separate_kernel": took[0] * 1e3}
 
     def verify(schedule):
         """Every rank: the same epochs on ONE engine (no sharding, no exchange) must give this replica bit for bit."""
@@ -256,18 +291,21 @@ def main():
         ref.set_param("hub_chunk", eng.get_param("hub_chunk"))  # the chunk is part of the summation order
         ref.srand(1)
         ref.init_embeddings(F._lib.INIT_SYMMETRIC if args.option in (5, 8, 11) else F._lib.INIT_UNIT)
-        for k in schedule:
-            ref.train(args.option, k, args.batch, 5, 0.02, 0)
+        for k, b in schedule:
+            ref.train(args.option, k, b, 5, 0.02, 0)
         same = bool(np.array_equal(ref.get_embeddings(), eng.get_embeddings()))
         ref.close()
         t = torch.tensor([1 if same else 0], dtype=torch.int32, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(t.item())
 
+    if use_dist and world > 1 and state["exchange"] == "push":
+        make_comm()
+        if state["exchange"] == "push":
+            tune_push()
     dt, st = timed(args.steps, args.warmup, args.batch)
     verified = None
     if use_dist and not args.no_verify:
-        schedule = ([args.warmup] if args.warmup > 0 else []) + [args.steps]
         verified = verify(schedule)
         if not verified and state["exchange"] == "push":
             # never report a number for wrong results: redo the whole measurement over the RCCL all-gather
@@ -277,6 +315,7 @@ def main():
             state["comm"], state["exchange"] = None, "allgather"
             eng.srand(1)
             eng.init_embeddings(F._lib.INIT_SYMMETRIC if args.option in (5, 8, 11) else F._lib.INIT_UNIT)
+            del schedule[:]
             dt, st = timed(args.steps, args.warmup, args.batch)
             verified = verify(schedule)
     value = nnz * args.steps / dt
@@ -298,7 +337,10 @@ def main():
         res["config"]["replicas_bit_identical_to_1gpu_run"] = verified
         if state["note"]:
             res["config"]["note"] = state["note"]
+        if state.get("tuned"):
+            res["config"]["push_autotune"] = state["tuned"]
         if state["exchange"] == "push":
+            res["config"]["push_fused"] = eng.get_param("push_fused")
             ps = eng.push_stats()
             res["config"]["rows_pushed_over_allgather_rows"] = ps["rows_pushed"] / max(ps["rows_allgather"], 1)
     if st is not None:
@@ -327,6 +369,14 @@ def main():
             k = max(1, args.steps // 2)
             extra["batch_%d" % b] = {"edges_per_s": nnz * k / dtb, "ms_per_epoch": dtb / k * 1e3,
                                      "hbm_GBs": stb["algorithmic_bytes"] / stb["device_seconds"] * 1e-9}
+        if extra:
+            res["extra"] = extra
+    if use_dist and world > 1:
+        extra = {}
+        for b in [int(x) for x in args.dist_extra_batches.split(",") if x]:
+            k = max(1, args.steps // 2)
+            dtb, _ = timed(k, 1, b)
+            extra["batch_%d" % b] = {"edges_per_s": nnz * k / dtb, "ms_per_epoch": dtb / k * 1e3}
         if extra:
             res["extra"] = extra
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -100,6 +100,7 @@ struct f2v_ctx {
         uint32_t *d_err = nullptr;
         unsigned long long seq = 0;
         int64_t timeout_ms = 20000;
+        bool fused = true;  // rows are pushed by the step / finalize kernels themselves ("push_fused" = 0: by a kernel after them)
         // reader masks: neighbour part cached per (batch, world), sampled vertices patched in per run
         std::vector<uint32_t> base_masks, patched_ids;
         uint32_t mask_batch = 0, mask_world = 0;
@@ -305,8 +306,10 @@ int math_of_option(int option) {
 }
 
 // Launch one minibatch step (+ hub finalisation) on the handle's stream.  d_ids: device sample ids.
+// push_masks / push: a sharded run's step -- the kernels also store every finished row into the second matrix of
+// the peers that read it (push_masks == nullptr: of every peer).
 int launch_step(f2v_ctx *c, int math, uint32_t batch_lo, uint32_t batch_hi, uint32_t row_lo, uint32_t row_hi,
-                const uint32_t *d_ids, uint32_t ns, float lr, int bs_mode) {
+                const uint32_t *d_ids, uint32_t ns, float lr, int bs_mode, bool push = false, const uint32_t *push_masks = nullptr) {
     int rc;
     if (c->upd_hi != c->upd_lo && batch_lo != c->upd_hi) {
         // not the continuation of the updated range (a new epoch, or batches out of order): swap / fold first
@@ -332,6 +335,13 @@ int launch_step(f2v_ctx *c, int math, uint32_t batch_lo, uint32_t batch_hi, uint
     a.ns = ns;
     a.bs_mode = bs_mode ? 1u : 0u;
     a.lr = lr;
+    push = push && c->push.attached && c->push.world > 1;
+    if (push) {
+        for (uint32_t r = 0; r < c->push.world; r++) a.push.peer[r] = c->push.peer_X[c->cur ^ 1][r];
+        a.push.masks = push_masks;
+        a.push.self = c->push.rank;
+        a.push.world = c->push.world;
+    }
 
     const uint32_t wpb = (uint32_t)c->waves_per_block;
     // sub-wave layout when D is 16, 32, 64, 128 or 256: 16, 8 or 4 work items per wavefront
@@ -342,8 +352,12 @@ int launch_step(f2v_ctx *c, int math, uint32_t batch_lo, uint32_t batch_hi, uint
     if (blocks == 0) {
         // nothing to compute here; the range bookkeeping below still advances
     } else if (quarter) {
-#define F2V_Q(OPT, LPI, NB, U) hipLaunchKernelGGL((qstep_kernel<OPT, LPI, NB, U>), dim3(blocks), dim3(64 * wpb), 0, c->stream, a)
-        // rows in flight per item: 4 at D = 128 (80 VGPRs, 6 waves/SIMD; 8 is selectable and measured 3-9 % slower
+#define F2V_Q(OPT, LPI, NB, U)                                                                                              \
+    do {                                                                                                                    \
+        if (push) hipLaunchKernelGGL((qstep_kernel<OPT, LPI, NB, U, true>), dim3(blocks), dim3(64 * wpb), 0, c->stream, a); \
+        else hipLaunchKernelGGL((qstep_kernel<OPT, LPI, NB, U, false>), dim3(blocks), dim3(64 * wpb), 0, c->stream, a);     \
+    } while (0)
+        // rows in flight per item: 4 at D = 128 (90 VGPRs, 5 waves/SIMD; 8 is selectable and measured 3-9 % slower
         // on RMAT-20: 116 VGPRs, 4 waves/SIMD) and at D = 256; 8 where a row is a single dwordx4 per lane (D <= 64)
         const bool u8 = (c->rows_in_flight == 8);
         const int o = (math == 5) ? 5 : 6;
@@ -378,6 +392,7 @@ int launch_step(f2v_ctx *c, int math, uint32_t batch_lo, uint32_t batch_hi, uint
         f.items = c->d_hubs + plan.fin_off[lev];
         f.n_items = plan.fin_cnt[lev];
         f.D = c->D;
+        f.push = a.push;
         const uint32_t fb = (f.n_items + 3) / 4;
         rc = dispatch_layout(c, [&](auto V, auto E) {
             constexpr int VEC = decltype(V)::value;
@@ -739,6 +754,10 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
         c->rows_in_flight = (int)value;
         return F2V_OK;
     }
+    if (!strcmp(name, "push_fused")) {
+        c->push.fused = value != 0;
+        return F2V_OK;
+    }
     if (!strcmp(name, "push_timeout_ms")) {
         if (value < 1 || value > 600000) return fail(F2V_EINVAL, "push_timeout_ms must be 1..600000");
         c->push.timeout_ms = value;
@@ -762,6 +781,7 @@ int f2v_get_param(f2v_handle c, const char *name, int64_t *out) {
     if (!strcmp(name, "use_graph")) { *out = c->use_graph ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "hub_chunk_auto")) { *out = c->chunk_auto ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "push_timeout_ms")) { *out = c->push.timeout_ms; return F2V_OK; }
+    if (!strcmp(name, "push_fused")) { *out = c->push.fused ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "push_world")) { *out = c->push.attached ? c->push.world : 0; return F2V_OK; }
     if (!strcmp(name, "push_rank")) { *out = c->push.rank; return F2V_OK; }
     if (!strcmp(name, "dim")) { *out = c->D; return F2V_OK; }
@@ -1109,9 +1129,9 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
             const uint32_t hi = (uint32_t)std::min<uint64_t>((uint64_t)lo + batch, n);
             uint32_t my_lo = lo, my_hi = hi;
             if (sharded) shard_of(lo, hi, c->push.rank, c->push.world, &my_lo, &my_hi);
-            if ((rc = launch_step(c, math, lo, hi, my_lo, my_hi, d_epoch_ids + (size_t)b * stride, ns, lr, bs_mode)) != F2V_OK) return rc;
+            if ((rc = launch_step(c, math, lo, hi, my_lo, my_hi, d_epoch_ids + (size_t)b * stride, ns, lr, bs_mode, exchanging && c->push.fused, d_masks)) != F2V_OK) return rc;
             if (exchanging) {
-                if ((rc = launch_push(c, c->cur ^ 1, d_masks, my_lo, my_hi)) != F2V_OK) return rc;
+                if (!c->push.fused && (rc = launch_push(c, c->cur ^ 1, d_masks, my_lo, my_hi)) != F2V_OK) return rc;
                 if ((rc = launch_barrier(c)) != F2V_OK) return rc;
                 c->push.rows_allgather += (uint64_t)(my_hi - my_lo) * (c->push.world - 1);
             }

@@ -56,6 +56,16 @@ constexpr uint32_t kItemFirst = 1u << 30;    // first chunk of its row (sigmoid:
 constexpr uint32_t kItemLast = 1u << 29;     // last chunk of its row: also takes the negative samples
 constexpr uint32_t kItemSlotMask = (1u << 28) - 1;
 
+constexpr int kMaxRanks = 8;  // multi-GPU push exchange: ranks of one xGMI hive
+
+// Where a rank's new rows go besides its own second matrix (sharded runs): the same matrix of every peer whose bit
+// is set in the row's reader mask.  world <= 1: nothing is pushed.
+struct PushTargets {
+    float *peer[kMaxRanks];   // second matrix of every rank, mapped through HIP IPC (peer[self] is not written)
+    const uint32_t *masks;    // per vertex: bit r = rank r reads the row; nullptr = every rank does
+    uint32_t self, world;
+};
+
 struct StepArgs {
     const float *X;              // current N x D embedding matrix (row-major, fp32): rows not yet updated this epoch
     float *Xn;                   // new matrix: rows of the updated range, and this batch's output
@@ -72,6 +82,7 @@ struct StepArgs {
     uint32_t ns;
     uint32_t bs_mode;
     float lr;
+    PushTargets push;
 };
 
 // One node of a hub row's combine tree: add partial rows [in_slot, in_slot+n) in order.
@@ -89,6 +100,7 @@ struct FinalizeArgs {
     const FinItem *items;
     uint32_t n_items;
     uint32_t D;
+    PushTargets push;
 };
 
 // ---- cross-lane primitives -------------------------------------------------------------------
@@ -188,6 +200,50 @@ __device__ __forceinline__ void store_row(float *dst, uint32_t lane, uint32_t D,
             const uint32_t d = lane * VEC + v;
             if (d < D) dst[d] = in[v];
         }
+    }
+}
+
+// A row store that is written through to the peer's memory: relaxed system-scope atomic stores carry the sc0 sc1
+// bits, so the data does not linger in this GPU's L2 and no cache write-back is needed afterwards.
+template <int VEC, bool EXACT>
+__device__ __forceinline__ void store_row_system(float *dst, uint32_t lane, uint32_t D, const float (&in)[VEC]) {
+    if constexpr (VEC >= 2) {
+        if (EXACT || D % VEC == 0) {
+            if (EXACT || lane * VEC < D) {
+                unsigned long long *q = reinterpret_cast<unsigned long long *>(dst + lane * VEC);
+#pragma unroll
+                for (int v = 0; v < VEC; v += 2) {
+                    const unsigned long long bits = (unsigned long long)__builtin_bit_cast(uint32_t, in[v]) |
+                                                    ((unsigned long long)__builtin_bit_cast(uint32_t, in[v + 1]) << 32);
+                    __hip_atomic_store(q + v / 2, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        const uint32_t d = lane * VEC + v;
+        if (d < D) __hip_atomic_store(reinterpret_cast<uint32_t *>(dst + d), __builtin_bit_cast(uint32_t, in[v]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+// 16 bytes per lane, written through at system scope (global_store_dwordx4 sc0 sc1): consecutive lanes write
+// consecutive 16-byte pieces, so a 16-lane item sends whole 256-byte runs down the link
+__device__ __forceinline__ void store16_system(float *p, const float4 v) {
+    const f32x4_t x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(x) : "memory");
+}
+
+// push one finished row (held by the wave, VEC values per lane) to the peers that read it
+template <int VEC, bool EXACT>
+__device__ __forceinline__ void push_row(const PushTargets &t, uint32_t row, uint32_t lane, uint32_t D, const float (&in)[VEC]) {
+    const uint32_t others = ((1u << t.world) - 1u) & ~(1u << t.self);
+    const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)((t.masks ? t.masks[row] : others) & others));
+#pragma unroll
+    for (int q = 0; q < kMaxRanks; ++q) {
+        if (m & (1u << q)) store_row_system<VEC, EXACT>(t.peer[q] + (size_t)row * D, lane, D, in);
     }
 }
 
@@ -324,6 +380,10 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
         }
     }
     store_row<VEC, EXACT>(out, lane, D, Y);
+    if (a.push.world > 1u) {  // sharded run: the new row also goes to the peers that read it
+        if (!partial) push_row<VEC, EXACT>(a.push, row, lane, D, Y);
+        __builtin_amdgcn_s_waitcnt(0);
+    }
 }
 
 // ---- sub-wave layout: LPI lanes per item, D = 4*LPI*NB ----------------------------------------------
@@ -460,7 +520,7 @@ __device__ __forceinline__ uint32_t wave_max_of_items(uint32_t v) {
     return m;
 }
 
-template <int OPT, int LPI, int NB, int U>
+template <int OPT, int LPI, int NB, int U, bool PUSH = false>
 __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
     constexpr uint32_t D = 4u * LPI * NB, IPW = 64u / LPI;  // dims; items per wavefront
     const uint32_t lane = threadIdx.x & 63u;
@@ -545,16 +605,33 @@ __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
 
     if (active) {
         float *out = (partial ? a.partials + (size_t)(it.flags & kItemSlotMask) * D : a.Xn + (size_t)row * D) + t * 4;
+        float4 v[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            float4 v;
             if (OPT == 5 && !partial)
-                v = make_float4(xi[b][0] + Y[b][0], xi[b][1] + Y[b][1], xi[b][2] + Y[b][2], xi[b][3] + Y[b][3]);  // algorithms.cpp:636
+                v[b] = make_float4(xi[b][0] + Y[b][0], xi[b][1] + Y[b][1], xi[b][2] + Y[b][2], xi[b][3] + Y[b][3]);  // algorithms.cpp:636
             else
-                v = make_float4(Y[b][0], Y[b][1], Y[b][2], Y[b][3]);
-            *reinterpret_cast<float4 *>(out + 4 * LPI * b) = v;
+                v[b] = make_float4(Y[b][0], Y[b][1], Y[b][2], Y[b][3]);
+            *reinterpret_cast<float4 *>(out + 4 * LPI * b) = v[b];
+        }
+        if constexpr (PUSH) {
+            // sharded run: the finished row goes, from registers, to the peers that read it (each item of the wave
+            // has its own row and reader mask: the loop over peers is predicated per lane group)
+            if (!partial) {
+                const uint32_t others = ((1u << a.push.world) - 1u) & ~(1u << a.push.self);
+                const uint32_t m = (a.push.masks ? a.push.masks[row] : others) & others;
+#pragma unroll
+                for (int q = 0; q < kMaxRanks; ++q) {
+                    if (m & (1u << q)) {
+                        float *dst = a.push.peer[q] + (size_t)row * D + t * 4;
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) store16_system(dst + 4 * LPI * b, v[b]);
+                    }
+                }
+            }
         }
     }
+    if constexpr (PUSH) __builtin_amdgcn_s_waitcnt(0);  // the peers' memory has acknowledged this wave's rows
 }
 
 // One level of the hub combine trees of a launch: every item adds up to `fanin` partial rows in
@@ -593,6 +670,10 @@ __global__ __launch_bounds__(256) void hub_finalize_kernel(const FinalizeArgs f)
             for (int v = 0; v < VEC; ++v) Y[v] = xi[v] + Y[v];
         }
         store_row<VEC, EXACT>(f.Xn + (size_t)h.row * D, lane, D, Y);
+        if (f.push.world > 1u) {
+            push_row<VEC, EXACT>(f.push, h.row, lane, D, Y);
+            __builtin_amdgcn_s_waitcnt(0);
+        }
     } else {
         store_row<VEC, EXACT>(f.partials + (size_t)h.out * D, lane, D, Y);
     }
@@ -620,7 +701,8 @@ __global__ __launch_bounds__(256) void commit_kernel(float *X, const float *Xn, 
 // peer, so all 7 links of a GPU carry traffic at once and nothing waits for a reply.  The stores are written
 // through at system scope and every wave waits for its acknowledgements: when the kernel has finished, its rows
 // are in the peers' memory.  (A release fence per wave instead -- buffer_wbl2 -- walks the whole L2 each time.)
-constexpr int kMaxRanks = 8;
+// The step and finalize kernels of a sharded run do the same from registers, while the row is still there (PUSH):
+// the transfer then overlaps the rest of the launch instead of following it.
 
 struct PushArgs {
     const float *src;         // local matrix that holds the new rows
@@ -629,31 +711,6 @@ struct PushArgs {
     uint32_t row_lo, rows;    // this rank's rows of the minibatch
     uint32_t D, self, world;
 };
-
-// A row store that is written through to the peer's memory: relaxed system-scope atomic stores carry the sc0 sc1
-// bits, so the data does not linger in this GPU's L2 and no cache write-back is needed afterwards.
-template <int VEC, bool EXACT>
-__device__ __forceinline__ void store_row_system(float *dst, uint32_t lane, uint32_t D, const float (&in)[VEC]) {
-    if constexpr (VEC >= 2) {
-        if (EXACT || D % VEC == 0) {
-            if (EXACT || lane * VEC < D) {
-                unsigned long long *q = reinterpret_cast<unsigned long long *>(dst + lane * VEC);
-#pragma unroll
-                for (int v = 0; v < VEC; v += 2) {
-                    const unsigned long long bits = (unsigned long long)__builtin_bit_cast(uint32_t, in[v]) |
-                                                    ((unsigned long long)__builtin_bit_cast(uint32_t, in[v + 1]) << 32);
-                    __hip_atomic_store(q + v / 2, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                }
-            }
-            return;
-        }
-    }
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-        const uint32_t d = lane * VEC + v;
-        if (d < D) __hip_atomic_store(reinterpret_cast<uint32_t *>(dst + d), __builtin_bit_cast(uint32_t, in[v]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
 
 template <int VEC, bool EXACT>
 __global__ __launch_bounds__(256) void push_rows_kernel(const PushArgs p) {

@@ -43,11 +43,14 @@ def _gloo_worker(rank, world, port, case, outdir, exchange="allgather"):
     eng = F.Engine(rp, ci, dim, device=0)
     eng.srand(1)
     eng.init_embeddings(0 if option in (5, 8, 11) else 1)
-    if exchange == "push":
+    if exchange in ("push", "push_unfused"):
         # the engine's own exchange: peers' matrices mapped through HIP IPC (here: other processes on the same GPU),
         # rows pushed by a HIP kernel, device-side flag barrier; gloo only carries the handles
         comm = fdist.PushExchange(dist, rank, world)
         eng.set_param("push_timeout_ms", 8000)
+        if exchange == "push_unfused":  # rows pushed by a kernel of their own behind the step instead of by the step itself
+            eng.set_param("push_fused", 0)
+            exchange = "push"
     elif exchange == "allgather":
         comm = fdist.HostStageComm(dist, rank, world)
     elif exchange == "need":
@@ -174,6 +177,16 @@ def _push_timeout_worker(rank, world, port, outdir):
     dist.barrier()
     eng.close()
     dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", [("cora.mtx", 5, 3, 256, 128, 0), ("pubmed.mtx", 6, 2, 4096, 128, 0), ("cora.mtx", 5, 2, 300, 100, 1)])
+def test_push_exchange_with_a_separate_push_kernel(case, tmp_path):
+    """ "push_fused" = 0: the same exchange with the rows copied to the peers by push_rows_kernel after the step."""
+    import torch.multiprocessing as mp
+    mp.spawn(_gloo_worker, args=(2, _free_port(), case, str(tmp_path), "push_unfused"), nprocs=2, join=True)
+    want = _single_twice(case)
+    for r in range(2):
+        assert np.array_equal(np.load(str(tmp_path / ("r%d.npy" % r))), want)
 
 
 def test_push_barrier_times_out_instead_of_hanging(tmp_path):
