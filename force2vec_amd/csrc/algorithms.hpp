@@ -7,9 +7,11 @@
 #define F2V_ALGORITHMS_HPP_
 #include <chrono>
 #include <cstdint>
+#include <cstdio>
 #include <iostream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "f2v.h"
@@ -62,6 +64,7 @@ class algorithms {
     bool binary_output = false;      // also write "<name>.bin": raw fp32 N x D (readBinEmbeddings format)
     bool text_output = true;         // the reference's text .embd (19 GB at 16 M x 128: switch off with -notext 1)
     f2v_stats stats{};
+    int rank = 0, world = 1;         // > 1 after join_ranks: one process per GPU, minibatch rows sharded (f2v_train_sharded)
 
     algorithms(CSRGraph &A_csr, std::string input, std::string outputd, INDEXTYPE dim, VALUETYPE /*gamma*/, INDEXTYPE /*bsize*/, int device = 0)
         : DIM(dim), rows(A_csr.rows), filename(input), outputdir(outputd) {
@@ -84,6 +87,42 @@ class algorithms {
     std::vector<VALUETYPE> AlgoForce2VecNSRWEFF_SREAL_D128_AVXZ(INDEXTYPE IT, INDEXTYPE TH, INDEXTYPE B, INDEXTYPE ns, VALUETYPE lr) { return run(10, 0, IT, B, ns, lr, "Force2VecWNSEFF Parallel Wall time required:"); }
     std::vector<VALUETYPE> AlgoForce2VecNSLB_SREAL_D128_AVXZ(INDEXTYPE IT, INDEXTYPE TH, INDEXTYPE B, INDEXTYPE ns, VALUETYPE lr) { return run(11, 0, IT, B, ns, lr, "Force2Vec Parallel Wall time required:"); }
 
+    // Multi-GPU: this process is rank `r` of `w` (one per GPU, all constructed on the same graph, seeded alike).
+    // The ranks swap the IPC handles of their matrices through files in `dir` (any directory they all see), map each
+    // other (f2v_push_attach) and run the self-test together; the option methods then train sharded and only
+    // rank 0 reports and writes the embedding.  No MPI, no torch: the exchange itself runs inside libf2v.
+    void join_ranks(int r, int w, const std::string &dir, double timeout_s = 120.0) {
+        if (w < 1 || w > F2V_PUSH_MAX_RANKS || r < 0 || r >= w) throw std::runtime_error("join_ranks: bad rank / world");
+        unsigned char mine[F2V_PUSH_EXPORT_BYTES];
+        check(f2v_push_export(h, mine));
+        auto path = [&](int k) { return dir + "/f2v_export." + std::to_string(k); };
+        {
+            const std::string tmp = path(r) + ".tmp";
+            FILE *f = fopen(tmp.c_str(), "wb");
+            if (!f || fwrite(mine, 1, sizeof mine, f) != sizeof mine || fclose(f) != 0 || rename(tmp.c_str(), path(r).c_str()) != 0)
+                throw std::runtime_error("join_ranks: cannot publish " + path(r));
+        }
+        std::vector<unsigned char> all((size_t)w * F2V_PUSH_EXPORT_BYTES);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int k = 0; k < w; k++) {
+            for (;;) {
+                FILE *f = fopen(path(k).c_str(), "rb");
+                if (f) {
+                    const size_t got = fread(all.data() + (size_t)k * F2V_PUSH_EXPORT_BYTES, 1, F2V_PUSH_EXPORT_BYTES, f);
+                    fclose(f);
+                    if (got == F2V_PUSH_EXPORT_BYTES) break;
+                }
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
+                    throw std::runtime_error("join_ranks: rank " + std::to_string(k) + " never published its handles in " + dir);
+                std::this_thread::sleep_for(std::chrono::milliseconds(2));
+            }
+        }
+        check(f2v_push_attach(h, (uint32_t)r, (uint32_t)w, all.data()));
+        check(f2v_push_selftest(h));
+        rank = r;
+        world = w;
+    }
+
     // writeToFile, sample/algorithms.h:118-136 (file name rule in f2v_output_name)
     void writeToFile(int option, int bs, INDEXTYPE B, INDEXTYPE IT, INDEXTYPE ns) {
         char name[4096];
@@ -104,12 +143,17 @@ class algorithms {
         auto t0 = std::chrono::steady_clock::now();
         const int math = (option == 5 || option == 8 || option == 11) ? 5 : 6;
         check(f2v_init_embeddings(h, math == 5 ? F2V_INIT_SYMMETRIC : F2V_INIT_UNIT));
-        check(f2v_train(h, option, IT, B, ns, lr, bs, &gpu_train_seconds));
+        if (world > 1)
+            check(f2v_train_sharded(h, option, IT, B, ns, lr, bs, &gpu_train_seconds));
+        else
+            check(f2v_train(h, option, IT, B, ns, lr, bs, &gpu_train_seconds));
         auto t1 = std::chrono::steady_clock::now();
         const double sec = std::chrono::duration<double>(t1 - t0).count();
-        std::cout << msg << sec << " seconds" << std::endl;
         f2v_get_stats(h, &stats);
-        writeToFile(option, bs, B, IT, ns);
+        if (rank == 0) {  // every replica is complete; one of them reports
+            std::cout << msg << sec << " seconds" << std::endl;
+            writeToFile(option, bs, B, IT, ns);
+        }
         return std::vector<VALUETYPE>{(VALUETYPE)sec};
     }
 };

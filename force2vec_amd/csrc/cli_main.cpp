@@ -4,7 +4,9 @@
 // accepted and unused (the force kernels run on the MI355X).
 // Extra flags: -device <int>, -seed <int> (default 1 = the reference's srand(1)), -cache 1 (keep / reuse a
 // binary CSR "<input>.f2vcsr"), -binout 1 (also write "<output>.embd.bin", raw fp32 N x D), -notext 1, -fastrng 1
-// (NON-parity fast mode: device-side initial embeddings and option-7 walks).
+// (NON-parity fast mode: device-side initial embeddings and option-7 walks), -gpus <n> (one forked process per GPU,
+// devices -device .. -device+n-1: every minibatch's rows sharded over them, new rows pushed over xGMI --
+// f2v_train_sharded; the ranks meet through files in a private temporary directory; same output, written by rank 0).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -12,6 +14,9 @@
 #include <iostream>
 #include <string>
 #include <thread>
+
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include "algorithms.hpp"
 
@@ -22,7 +27,7 @@ namespace {
 struct Settings {
     std::string input, output;
     long batch = 384, iter = 1200, threads = (long)std::thread::hardware_concurrency(), dim = 128, nsamples = 5, option = 5, bs = 0;
-    long device = 0, seed = 1, cache = 0, binout = 0, fastrng = 0, notext = 0;
+    long device = 0, seed = 1, cache = 0, binout = 0, fastrng = 0, notext = 0, gpus = 1, samegpu = 0;
     double gamma = 1.0, lr = 0.02;
 };
 
@@ -80,6 +85,8 @@ int main(int argc, char *argv[]) {
         {"-cache", Kind::Integer, &s.cache, "<int>, 1 = keep / reuse the binary CSR <input>.f2vcsr."},
         {"-binout", Kind::Integer, &s.binout, "<int>, 1 = also write <output file>.bin, raw fp32 N x D (the scorers' binary embedding format)."},
         {"-notext", Kind::Integer, &s.notext, "<int>, 1 = skip the text .embd (use with -binout 1 for very large graphs)."},
+        {"-gpus", Kind::Integer, &s.gpus, "<int>, number of GPUs (1..8): one process per GPU from -device on, minibatch rows sharded, rows exchanged over xGMI. (default:1)"},
+        {"-samegpu", Kind::Integer, &s.samegpu, "<int>, 1 = all ranks of a -gpus run on device -device (self-test on a one-GPU machine)."},
         {"-fastrng", Kind::Integer, &s.fastrng, "<int>, 1 = NON-PARITY fast mode: initial embeddings and option-7 walks from a device-side RNG."},
     };
     const size_t nflags = sizeof flags / sizeof flags[0];
@@ -112,21 +119,61 @@ int main(int argc, char *argv[]) {
         printf("-batch and -dim must be positive, -iter and -nsamples non-negative.\n");
         return 1;
     }
+    if (s.gpus < 1 || s.gpus > F2V_PUSH_MAX_RANKS) {
+        printf("-gpus must be 1..%d.\n", F2V_PUSH_MAX_RANKS);
+        return 1;
+    }
     std::vector<VALUETYPE> seconds;
+    int rank = 0;
+    std::string meet;  // directory the ranks of a -gpus run meet in
     try {
         CSRGraph graph;
-        SetInputMatricesAsCSR(graph, s.input, s.cache != 0);
-        algorithms algo(graph, s.input, s.output, (INDEXTYPE)s.dim, (VALUETYPE)s.gamma, (INDEXTYPE)s.batch, (int)s.device);
-        algo.binary_output = s.binout != 0;
-        algo.text_output = s.notext == 0;
-        if (s.fastrng && f2v_set_param(algo.h, "fast_rng", 1) != F2V_OK) throw std::runtime_error(f2v_last_error());
-        algo.srand((unsigned)s.seed);
-        std::cout << "Running: " << variant->name << std::endl;
-        auto method = (s.bs != 0 && variant->with_bs) ? variant->with_bs : variant->plain;
-        seconds = (algo.*method)((INDEXTYPE)s.iter, (INDEXTYPE)s.threads, (INDEXTYPE)s.batch, (INDEXTYPE)s.nsamples, (VALUETYPE)s.lr);
-        const double t = algo.gpu_train_seconds;
-        printf("GPU epoch loop: %.6f s, %.4g nnz/s, %.1f GB/s algorithmic\n", t, t > 0 ? algo.stats.nnz / t : 0.0,
-               t > 0 ? algo.stats.algorithmic_bytes / t * 1e-9 : 0.0);
+        SetInputMatricesAsCSR(graph, s.input, s.cache != 0);  // host only: read once, inherited by the forked ranks
+        std::vector<pid_t> kids;
+        if (s.gpus > 1) {
+            char tmpl[] = "/tmp/f2v_ranks_XXXXXX";
+            if (!mkdtemp(tmpl)) throw std::runtime_error("cannot create a meeting directory under /tmp");
+            meet = tmpl;
+            fflush(nullptr);
+            // no HIP call has been made yet: every rank initialises its own GPU after the fork
+            for (int r = 1; r < s.gpus; r++) {
+                const pid_t pid = fork();
+                if (pid < 0) throw std::runtime_error("fork failed");
+                if (pid == 0) { rank = r; kids.clear(); break; }
+                kids.push_back(pid);
+            }
+        }
+        int rc_mine = 0;
+        try {
+            algorithms algo(graph, s.input, s.output, (INDEXTYPE)s.dim, (VALUETYPE)s.gamma, (INDEXTYPE)s.batch, (int)s.device + (s.samegpu ? 0 : rank));
+            algo.binary_output = s.binout != 0;
+            algo.text_output = s.notext == 0;
+            if (s.fastrng && f2v_set_param(algo.h, "fast_rng", 1) != F2V_OK) throw std::runtime_error(f2v_last_error());
+            algo.srand((unsigned)s.seed);
+            if (s.gpus > 1) algo.join_ranks(rank, (int)s.gpus, meet);
+            if (rank == 0) std::cout << "Running: " << variant->name << std::endl;
+            auto method = (s.bs != 0 && variant->with_bs) ? variant->with_bs : variant->plain;
+            seconds = (algo.*method)((INDEXTYPE)s.iter, (INDEXTYPE)s.threads, (INDEXTYPE)s.batch, (INDEXTYPE)s.nsamples, (VALUETYPE)s.lr);
+            const double t = algo.gpu_train_seconds;
+            if (rank == 0 && s.gpus == 1)
+                printf("GPU epoch loop: %.6f s, %.4g nnz/s, %.1f GB/s algorithmic\n", t, t > 0 ? algo.stats.nnz / t : 0.0,
+                       t > 0 ? algo.stats.algorithmic_bytes / t * 1e-9 : 0.0);
+            else if (rank == 0)
+                printf("GPU epoch loop: %.6f s, %.4g nnz/s on %ld GPUs\n", t, t > 0 ? (double)graph.nnz * (double)s.iter / t : 0.0, s.gpus);
+        } catch (const std::exception &e) {
+            fprintf(stderr, "Force2Vec%s: %s\n", s.gpus > 1 ? (" [rank " + std::to_string(rank) + "]").c_str() : "", e.what());
+            rc_mine = 2;
+        }
+        if (rank != 0) _exit(rc_mine);  // a forked rank: nothing of the parent's to unwind
+        for (pid_t pid : kids) {
+            int st = 0;
+            if (waitpid(pid, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) rc_mine = 2;
+        }
+        if (!meet.empty()) {
+            for (int r = 0; r < s.gpus; r++) (void)remove((meet + "/f2v_export." + std::to_string(r)).c_str());
+            (void)rmdir(meet.c_str());
+        }
+        if (rc_mine) return rc_mine;
     } catch (const std::exception &e) {
         fprintf(stderr, "Force2Vec: %s\n", e.what());
         return 2;

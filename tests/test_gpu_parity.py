@@ -331,6 +331,28 @@ def test_cli_drop_in(F, tmp_path):
     assert np.abs(got - O.read_embd(str(tmp_path / "ref.embd"))).max() < 3e-5
 
 
+@pytest.mark.parametrize("gpus,option", [(2, 5), (3, 6), (2, 7)])
+def test_cli_gpus_flag_runs_one_process_per_rank(F, tmp_path, gpus, option):
+    """./bin/Force2Vec -gpus N: N forked ranks (here all on the one card: -samegpu 1) meet through files, map each
+    other's matrices (HIP IPC), train sharded with the push exchange; rank 0 writes the same bytes as the 1-GPU run."""
+    exe = os.path.join(ROOT, "bin", "Force2Vec")
+    outs = []
+    for g in (1, gpus):
+        out = str(tmp_path / ("g%d" % g)) + "/"
+        os.makedirs(out)
+        r = subprocess.run([exe, "-input", golden_graph_path("cora.mtx"), "-output", out, "-iter", "6", "-batch", "300", "-dim", "128",
+                            "-option", str(option), "-gpus", str(g), "-samegpu", "1"], cwd=out, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert r.stdout.count("Wall time required") == 1 and r.stdout.count("Running:") == 1  # one rank reports
+        files = [f for f in os.listdir(out) if f.endswith(".embd")]
+        assert len(files) == 1
+        outs.append(open(out + files[0], "rb").read())
+        assert len(open(out + "Results.txt").read().splitlines()) == 1
+    assert outs[0] == outs[1]
+    r = subprocess.run([exe, "-input", golden_graph_path("cora.mtx"), "-gpus", "9"], capture_output=True, text=True)
+    assert r.returncode == 1 and "-gpus must be" in r.stdout
+
+
 def test_cli_binary_cache_and_output(F, tmp_path):
     exe = os.path.join(ROOT, "bin", "Force2Vec")
     out = str(tmp_path) + "/"
