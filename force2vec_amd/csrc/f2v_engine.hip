@@ -1026,8 +1026,11 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
             drop_plans(c);
         }
     }
-    for (uint32_t b = 0; b < nb; b++)  // all launch plans up-front: one upload, no syncs inside the timed loop
-        (void)plan_for(c, b * batch, (uint32_t)std::min<uint64_t>((uint64_t)b * batch + batch, n), math == 7);
+    for (uint32_t b = 0; b < nb; b++) {  // all launch plans up-front: one upload, no syncs inside the timed loop
+        uint32_t lo = b * batch, hi = (uint32_t)std::min<uint64_t>((uint64_t)b * batch + batch, n);
+        if (sharded) shard_of(lo, hi, c->push.rank, c->push.world, &lo, &hi);
+        (void)plan_for(c, lo, hi, math == 7);
+    }
     if ((rc = upload_plans(c)) != F2V_OK) return rc;
     // Sample ids do not depend on the embeddings: options 5/6 pre-draw every epoch's ids (as long
     // as that stays below 1 GiB); option 7 interleaves walk generation, so it goes epoch by epoch.
