@@ -67,6 +67,9 @@ struct f2v_ctx {
     uint32_t *d_rowptr = nullptr, *d_colids = nullptr, *d_walks = nullptr, *d_ids = nullptr;
     size_t ids_cap = 0, ids_valid = 0;  // ids_valid: prefix uploaded by f2v_upload_sample_ids
     float *d_X[2] = {nullptr, nullptr}, *d_partials = nullptr, *d_table = nullptr;
+    uint32_t *d_ready = nullptr, *d_kerr = nullptr;  // combine-tree flags (one per partial slot), kernel error word
+    uint32_t launch_seq = 0;
+    bool merge_fin = true, capturing = false;  // all combine-tree levels in one launch (not while a hipGraph is captured)
     int cur = 0;  // d_X[cur]: current matrix; d_X[cur^1]: receives the rows updated this epoch
     bool have_x = false, have_walks = false;
     Rand rng;
@@ -228,6 +231,10 @@ int upload_plans(f2v_ctx *c) {
         if (c->d_partials) (void)hipFree(c->d_partials);
         c->d_partials = nullptr;
         HIPC(hipMalloc((void **)&c->d_partials, need_slots * (size_t)c->D * sizeof(float)));
+        if (c->d_ready) (void)hipFree(c->d_ready);
+        c->d_ready = nullptr;
+        HIPC(hipMalloc((void **)&c->d_ready, need_slots * sizeof(uint32_t)));
+        HIPC(hipMemset(c->d_ready, 0, need_slots * sizeof(uint32_t)));
         c->partial_slots = need_slots;
     }
     if (c->h_items.size() > c->d_items_valid)
@@ -296,6 +303,14 @@ int flush_pending(f2v_ctx *c) {
     return F2V_OK;
 }
 
+// after a stream synchronisation: did a kernel give up a bounded wait?
+int check_kernel_err(f2v_ctx *c, const char *where) {
+    uint32_t e = 0;
+    HIPC(hipMemcpy(&e, c->d_kerr, sizeof e, hipMemcpyDeviceToHost));
+    if (e) return fail(F2V_ESTATE, "%s: a combine-tree node waited for its inputs in vain (code %u); set \"merge_finalize\" = 0", where, e);
+    return F2V_OK;
+}
+
 int math_of_option(int option) {
     switch (option) {
         case 5: case 8: case 11: return 5;
@@ -348,7 +363,21 @@ int launch_step(f2v_ctx *c, int math, uint32_t batch_lo, uint32_t batch_hi, uint
     const bool quarter = c->use_quarter && (c->D == 16 || c->D == 32 || c->D == 64 || c->D == 128 || c->D == 256);
     const uint32_t per_wave = !quarter ? 1u : (c->D == 16 ? 16u : c->D == 32 ? 8u : 4u);
     const uint32_t waves = (plan.n_items + per_wave - 1) / per_wave;
-    const uint32_t blocks = (waves + wpb - 1) / wpb;  // 0 when this rank has no row of the batch
+    uint32_t blocks = (waves + wpb - 1) / wpb;  // 0 when this rank has no row of the batch
+    a.step_blocks = blocks;
+    // sub-wave kernel: the combine trees ride in the same grid (one launch per minibatch)
+    const bool fused_tree = quarter && c->merge_fin && !c->capturing && plan.n_levels >= 1 && blocks > 0;
+    if (fused_tree) {
+        a.fin_items = c->d_hubs + plan.fin_off[0];
+        a.fin_n = 0;
+        for (int lev = 0; lev < plan.n_levels; lev++) a.fin_n += plan.fin_cnt[lev];  // the levels are stored back to back
+        a.ready = c->d_ready;
+        a.err = c->d_kerr;
+        a.timeout_ticks = 500000000ull;  // 5 s of the 100 MHz wall clock
+        a.seq = ++c->launch_seq;
+        if (a.seq == 0) a.seq = ++c->launch_seq;  // 0 is what fresh flags hold
+        blocks += (a.fin_n + wpb - 1) / wpb;
+    }
     if (blocks == 0) {
         // nothing to compute here; the range bookkeeping below still advances
     } else if (quarter) {
@@ -384,7 +413,36 @@ int launch_step(f2v_ctx *c, int math, uint32_t batch_lo, uint32_t batch_hi, uint
         if (rc != F2V_OK) return rc;
     }
     HIPC(hipGetLastError());
-    for (int lev = 0; lev < plan.n_levels; lev++) {
+    const bool tree = !fused_tree && c->merge_fin && !c->capturing && plan.n_levels >= 2;
+    if (tree) {
+        FinalizeTreeArgs t{};
+        t.f.X = a.X;
+        t.f.partials = c->d_partials;
+        t.f.Xn = a.Xn;
+        t.f.items = c->d_hubs + plan.fin_off[0];
+        t.f.n_items = 0;
+        for (int lev = 0; lev < plan.n_levels; lev++) t.f.n_items += plan.fin_cnt[lev];  // the levels are stored back to back
+        t.f.D = c->D;
+        t.f.push = a.push;
+        t.ready = c->d_ready;
+        t.err = c->d_kerr;
+        t.timeout_ticks = 500000000ull;  // 5 s of the 100 MHz wall clock
+        t.seq = ++c->launch_seq;
+        if (t.seq == 0) t.seq = ++c->launch_seq;  // 0 is what fresh flags hold
+        t.first_dep = plan.fin_cnt[0];
+        const uint32_t fb = (t.f.n_items + 3) / 4;
+        rc = dispatch_layout(c, [&](auto V, auto E) {
+            constexpr int VEC = decltype(V)::value;
+            constexpr bool EX = decltype(E)::value;
+            if (math == 5)
+                hipLaunchKernelGGL((hub_finalize_tree_kernel<5, VEC, EX>), dim3(fb), dim3(256), 0, c->stream, t);
+            else
+                hipLaunchKernelGGL((hub_finalize_tree_kernel<6, VEC, EX>), dim3(fb), dim3(256), 0, c->stream, t);
+        });
+        if (rc != F2V_OK) return rc;
+        HIPC(hipGetLastError());
+    }
+    for (int lev = 0; lev < plan.n_levels && !tree && !fused_tree; lev++) {
         FinalizeArgs f{};
         f.X = a.X;
         f.partials = c->d_partials;
@@ -607,6 +665,8 @@ int f2v_create(const uint32_t *rowptr, const uint32_t *colids, uint32_t n, uint6
     HIPB(hipMalloc((void **)&c->d_colids, std::max<size_t>(nnz, 1) * sizeof(uint32_t)));
     for (int k = 0; k < 2; k++) HIPB(hipMalloc((void **)&c->d_X[k], ((size_t)n + kPadRows) * dim * sizeof(float)));
     HIPB(hipMalloc((void **)&c->d_table, kSmTableSize * sizeof(float)));
+    HIPB(hipMalloc((void **)&c->d_kerr, 64));
+    HIPB(hipMemset(c->d_kerr, 0, 64));
     HIPB(hipMemcpy(c->d_rowptr, rowptr, ((size_t)n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
     if (nnz) HIPB(hipMemcpy(c->d_colids, colids, nnz * sizeof(uint32_t), hipMemcpyHostToDevice));
     float table[kSmTableSize];
@@ -622,7 +682,7 @@ int f2v_destroy(f2v_handle c) {
     (void)hipSetDevice(c->device);
     (void)push_detach(c);
     void *ptrs[] = {c->d_rowptr, c->d_colids, c->d_walks, c->d_ids, c->d_X[0], c->d_X[1],
-                    c->d_partials, c->d_table, c->d_items, c->d_hubs, c->push.flags, c->push.d_err, c->push.d_masks, c->push.d_patch};
+                    c->d_partials, c->d_table, c->d_items, c->d_hubs, c->d_ready, c->d_kerr, c->push.flags, c->push.d_err, c->push.d_masks, c->push.d_patch};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -696,6 +756,7 @@ int f2v_get_embeddings(f2v_handle c, float *x_out) {
     int rc = flush_pending(c);
     if (rc != F2V_OK) return rc;
     HIPC(hipStreamSynchronize(c->stream));
+    if ((rc = check_kernel_err(c, "f2v_get_embeddings")) != F2V_OK) return rc;
     HIPC(hipMemcpy(x_out, c->d_X[c->cur], (size_t)c->n * c->D * sizeof(float), hipMemcpyDeviceToHost));
     return F2V_OK;
 }
@@ -758,6 +819,10 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
         c->push.fused = value != 0;
         return F2V_OK;
     }
+    if (!strcmp(name, "merge_finalize")) {
+        c->merge_fin = value != 0;
+        return F2V_OK;
+    }
     if (!strcmp(name, "push_timeout_ms")) {
         if (value < 1 || value > 600000) return fail(F2V_EINVAL, "push_timeout_ms must be 1..600000");
         c->push.timeout_ms = value;
@@ -782,6 +847,7 @@ int f2v_get_param(f2v_handle c, const char *name, int64_t *out) {
     if (!strcmp(name, "hub_chunk_auto")) { *out = c->chunk_auto ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "push_timeout_ms")) { *out = c->push.timeout_ms; return F2V_OK; }
     if (!strcmp(name, "push_fused")) { *out = c->push.fused ? 1 : 0; return F2V_OK; }
+    if (!strcmp(name, "merge_finalize")) { *out = c->merge_fin ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "push_world")) { *out = c->push.attached ? c->push.world : 0; return F2V_OK; }
     if (!strcmp(name, "push_rank")) { *out = c->push.rank; return F2V_OK; }
     if (!strcmp(name, "dim")) { *out = c->D; return F2V_OK; }
@@ -895,7 +961,7 @@ int f2v_flush(f2v_handle c) {
     int rc = flush_pending(c);
     if (rc != F2V_OK) return rc;
     HIPC(hipStreamSynchronize(c->stream));
-    return F2V_OK;
+    return check_kernel_err(c, "f2v_flush");
 }
 
 int f2v_synchronize(f2v_handle c) {
@@ -1084,12 +1150,14 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
         hipGraphExec_t exec[2] = {nullptr, nullptr};
         for (int par = 0; par < 2; par++) {
             HIPC(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            c->capturing = true;  // a replayed launch cannot carry a fresh sequence number: one launch per tree level
             for (uint32_t b = 0; b < nb && rc == F2V_OK; b++) {
                 const uint32_t lo = b * batch;
                 const uint32_t hi = (uint32_t)std::min<uint64_t>((uint64_t)lo + batch, n);
                 rc = launch_step(c, math, lo, hi, lo, hi, c->d_ids + (size_t)par * per_epoch + (size_t)b * stride, ns, lr, bs_mode);
             }
             hipError_t e = hipStreamEndCapture(c->stream, &graph[par]);
+            c->capturing = false;
             if (rc != F2V_OK) return rc;
             HIPC(e);
             HIPC(hipGraphInstantiate(&exec[par], graph[par], nullptr, nullptr, 0));
@@ -1161,6 +1229,7 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
     (void)hipEventDestroy(ev1);
     c->stats.device_seconds = ms * 1e-3;
     if (seconds_out) *seconds_out = ms * 1e-3;
+    if ((rc = check_kernel_err(c, sharded ? "f2v_train_sharded" : "f2v_train")) != F2V_OK) return rc;
     if (exchanging) return check_push_err(c, "f2v_train_sharded");
     return F2V_OK;
 }

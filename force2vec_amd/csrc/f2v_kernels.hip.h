@@ -56,6 +56,14 @@ constexpr uint32_t kItemFirst = 1u << 30;    // first chunk of its row (sigmoid:
 constexpr uint32_t kItemLast = 1u << 29;     // last chunk of its row: also takes the negative samples
 constexpr uint32_t kItemSlotMask = (1u << 28) - 1;
 
+// One node of a hub row's combine tree: add partial rows [in_slot, in_slot+n) in order.
+struct FinItem {
+    uint32_t in_slot, n;
+    uint32_t out;  // partial slot of the sum, or kFinToStage: it is the row's total -> stage the new row
+    uint32_t row;
+};
+constexpr uint32_t kFinToStage = 0xFFFFFFFFu;
+
 constexpr int kMaxRanks = 8;  // multi-GPU push exchange: ranks of one xGMI hive
 
 // Where a rank's new rows go besides its own second matrix (sharded runs): the same matrix of every peer whose bit
@@ -83,15 +91,15 @@ struct StepArgs {
     uint32_t bs_mode;
     float lr;
     PushTargets push;
+    // sub-wave kernel only: the combine trees of this launch's hub rows run in the same grid, behind the step items
+    const FinItem *fin_items;         // all levels, lowest first; nullptr: the trees run as launches of their own
+    uint32_t fin_n;
+    uint32_t step_blocks;             // workgroups [0, step_blocks) step items, the rest run tree nodes
+    uint32_t seq;                     // this launch's sequence number for the ready flags
+    uint32_t *ready;
+    uint32_t *err;
+    unsigned long long timeout_ticks;
 };
-
-// One node of a hub row's combine tree: add partial rows [in_slot, in_slot+n) in order.
-struct FinItem {
-    uint32_t in_slot, n;
-    uint32_t out;  // partial slot of the sum, or kFinToStage: it is the row's total -> stage the new row
-    uint32_t row;
-};
-constexpr uint32_t kFinToStage = 0xFFFFFFFFu;
 
 struct FinalizeArgs {
     const float *X;
@@ -234,6 +242,12 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store16_system(float *p, const float4 v) {
     const f32x4_t x = {v.x, v.y, v.z, v.w};
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(x) : "memory");
+}
+
+// the same written through at agent scope (sc1): visible to the other XCDs' L2s once acknowledged
+__device__ __forceinline__ void store16_agent(float *p, const float4 v) {
+    const f32x4_t x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(x) : "memory");
 }
 
 // push one finished row (held by the wave, VEC values per lane) to the peers that read it
@@ -386,6 +400,147 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
     }
 }
 
+// ---- all levels of the combine trees in ONE launch ---------------------------------------------------------
+// The upper levels of the trees hold a handful of nodes (the rows with more than `fanin` chunks), so a launch per
+// level is pure launch latency on the critical path of every minibatch.  hub_finalize_tree_kernel runs every
+// level's nodes in one grid, lowest level first: a node of an upper level waits until the nodes it adds have
+// announced their sums -- ready[slot] == seq, the launch's sequence number -- which they do after storing them
+// written through at agent scope (sc1: visible to every XCD's L2) and waiting for the stores to be acknowledged.
+// Forward progress: a node only ever waits for nodes with a SMALLER index, and workgroups are dispatched in index
+// order, so whatever a wave waits for is already running or done; every wait is bounded all the same (err = 2).
+// The sub-wave step kernel goes one step further and appends the trees to its OWN grid (StepArgs::tree): the hub
+// pieces announce their partial sums the same way, and a minibatch is ONE launch.
+struct FinalizeTreeArgs {
+    FinalizeArgs f;           // items: all levels, lowest first; n_items: all of them
+    uint32_t *ready;          // per partial slot: sequence number of the launch that last produced it
+    uint32_t *err;
+    unsigned long long timeout_ticks;
+    uint32_t seq;
+    uint32_t first_dep;       // items from this index on add sums produced INSIDE this launch
+};
+
+template <int VEC, bool EXACT>
+__device__ __forceinline__ void load_row_agent(const float *src, uint32_t lane, uint32_t D, float (&out)[VEC]) {
+    if constexpr (VEC >= 2) {
+        if (EXACT || D % VEC == 0) {
+            if (EXACT || lane * VEC < D) {
+                const unsigned long long *q = reinterpret_cast<const unsigned long long *>(src + lane * VEC);
+#pragma unroll
+                for (int v = 0; v < VEC; v += 2) {
+                    const unsigned long long bits = __hip_atomic_load(q + v / 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    out[v] = __builtin_bit_cast(float, (uint32_t)bits);
+                    out[v + 1] = __builtin_bit_cast(float, (uint32_t)(bits >> 32));
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) out[v] = 0.0f;
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        const uint32_t d = lane * VEC + v;
+        out[v] = d < D ? __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const uint32_t *>(src + d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0f;
+    }
+}
+
+template <int VEC, bool EXACT>
+__device__ __forceinline__ void store_row_agent(float *dst, uint32_t lane, uint32_t D, const float (&in)[VEC]) {
+    if constexpr (VEC >= 2) {
+        if (EXACT || D % VEC == 0) {
+            if (EXACT || lane * VEC < D) {
+                unsigned long long *q = reinterpret_cast<unsigned long long *>(dst + lane * VEC);
+#pragma unroll
+                for (int v = 0; v < VEC; v += 2) {
+                    const unsigned long long bits = (unsigned long long)__builtin_bit_cast(uint32_t, in[v]) |
+                                                    ((unsigned long long)__builtin_bit_cast(uint32_t, in[v + 1]) << 32);
+                    __hip_atomic_store(q + v / 2, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        const uint32_t d = lane * VEC + v;
+        if (d < D) __hip_atomic_store(reinterpret_cast<uint32_t *>(dst + d), __builtin_bit_cast(uint32_t, in[v]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Y = p[0] + p[1] + ... + p[n-1] in order, 16 row loads in flight; COHERENT: the rows were produced inside this launch
+template <int VEC, bool EXACT, bool COHERENT>
+__device__ __forceinline__ void add_partials(const float *p, uint32_t n, uint32_t lane, uint32_t D, float (&Y)[VEC]) {
+    if constexpr (COHERENT) load_row_agent<VEC, EXACT>(p, lane, D, Y);
+    else load_row<VEC, EXACT>(p, lane, D, Y);
+    constexpr int U = 16;
+    for (uint32_t c = 1; c < n; c += U) {
+        float P[U][VEC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t k = (c + u) < n ? (c + u) : (n - 1);
+            if constexpr (COHERENT) load_row_agent<VEC, EXACT>(p + (size_t)k * D, lane, D, P[u]);
+            else load_row<VEC, EXACT>(p + (size_t)k * D, lane, D, P[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (c + u < n) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) Y[v] = Y[v] + P[u][v];
+            }
+        }
+    }
+}
+
+// one node of the trees: wave `w` of the nodes' part of a grid
+template <int OPT, int VEC, bool EXACT>
+__device__ __forceinline__ void finalize_tree_node(const FinalizeTreeArgs &a, uint32_t w, uint32_t lane) {
+    const FinalizeArgs &f = a.f;
+    if (w >= f.n_items) return;
+    const FinItem h = f.items[w];
+    const uint32_t D = f.D;
+    const float *p = f.partials + (size_t)h.in_slot * D;
+    float Y[VEC];
+    if (w >= a.first_dep) {
+        const unsigned long long t0 = wall_clock64();
+        for (uint32_t c = lane; c < h.n; c += 64u) {
+            while (__hip_atomic_load(a.ready + h.in_slot + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.seq) {
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t0 > a.timeout_ticks) {
+                    __hip_atomic_store(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        add_partials<VEC, EXACT, true>(p, h.n, lane, D, Y);
+    } else {
+        add_partials<VEC, EXACT, false>(p, h.n, lane, D, Y);
+    }
+    if (h.out == kFinToStage) {
+        if constexpr (OPT == 5) {
+            float xi[VEC];
+            load_row<VEC, EXACT>(f.X + (size_t)h.row * D, lane, D, xi);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) Y[v] = xi[v] + Y[v];
+        }
+        store_row<VEC, EXACT>(f.Xn + (size_t)h.row * D, lane, D, Y);
+        if (f.push.world > 1u) {
+            push_row<VEC, EXACT>(f.push, h.row, lane, D, Y);
+            __builtin_amdgcn_s_waitcnt(0);
+        }
+    } else {
+        store_row_agent<VEC, EXACT>(f.partials + (size_t)h.out * D, lane, D, Y);
+        __builtin_amdgcn_s_waitcnt(0);  // the sum is in memory before it is announced
+        if (lane == 0) __hip_atomic_store(a.ready + h.out, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int OPT, int VEC, bool EXACT>
+__global__ __launch_bounds__(256) void hub_finalize_tree_kernel(const FinalizeTreeArgs a) {
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    finalize_tree_node<OPT, VEC, EXACT>(a, w, threadIdx.x & 63u);
+}
+
 // ---- sub-wave layout: LPI lanes per item, D = 4*LPI*NB ----------------------------------------------
 // 64/LPI work items per wavefront, each on LPI consecutive lanes of a 16-lane DPP row: LPI = 16 with NB = 1, 2, 4
 // blocks (D = 64, 128, 256: four items per wavefront, the "quarter-wave" layout of the flagship D = 128), LPI = 8
@@ -526,6 +681,18 @@ __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t t = lane & (LPI - 1u), q = lane / LPI;
     const uint32_t wpb = blockDim.x >> 6;
+    if (blockIdx.x >= a.step_blocks) {
+        // the tail of the grid: one wavefront per node of the combine trees of this launch's hub rows; every node
+        // waits for the partial sums it adds (hub pieces below announce theirs through the same flags)
+        constexpr int FVEC = D >= 64u ? (int)(D / 64u) : 1;
+        FinalizeTreeArgs ft;
+        ft.f.X = a.X; ft.f.partials = a.partials; ft.f.Xn = a.Xn; ft.f.items = a.fin_items; ft.f.n_items = a.fin_n; ft.f.D = D;
+        ft.f.push = a.push;
+        ft.ready = a.ready; ft.err = a.err; ft.timeout_ticks = a.timeout_ticks; ft.seq = a.seq; ft.first_dep = 0u;
+        const uint32_t node = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x - a.step_blocks) * wpb + (threadIdx.x >> 6)));
+        finalize_tree_node<OPT, FVEC, (D % 64u == 0u)>(ft, node, lane);
+        return;
+    }
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + (threadIdx.x >> 6)));
 
     // The minibatch's negative samples are the same ns rows for every item (except with -bs 1): the workgroup
@@ -612,7 +779,8 @@ __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
                 v[b] = make_float4(xi[b][0] + Y[b][0], xi[b][1] + Y[b][1], xi[b][2] + Y[b][2], xi[b][3] + Y[b][3]);  // algorithms.cpp:636
             else
                 v[b] = make_float4(Y[b][0], Y[b][1], Y[b][2], Y[b][3]);
-            *reinterpret_cast<float4 *>(out + 4 * LPI * b) = v[b];
+            if (partial && a.fin_items) store16_agent(out + 4 * LPI * b, v[b]);  // a tree node of this grid reads it
+            else *reinterpret_cast<float4 *>(out + 4 * LPI * b) = v[b];
         }
         if constexpr (PUSH) {
             // sharded run: the finished row goes, from registers, to the peers that read it (each item of the wave
@@ -632,6 +800,10 @@ __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
         }
     }
     if constexpr (PUSH) __builtin_amdgcn_s_waitcnt(0);  // the peers' memory has acknowledged this wave's rows
+    if (a.fin_items) {
+        __builtin_amdgcn_s_waitcnt(0);  // partial sums are in memory before they are announced
+        if (active && partial && t == 0u) __hip_atomic_store(a.ready + (it.flags & kItemSlotMask), a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // One level of the hub combine trees of a launch: every item adds up to `fanin` partial rows in

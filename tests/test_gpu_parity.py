@@ -110,15 +110,18 @@ def test_minibatch_steps_bit_exact(F, option, dim, bs, chunk, n, batch):
 
 
 @pytest.mark.parametrize("option", [5, 6])
+@pytest.mark.parametrize("merge", [1, 0])
 @pytest.mark.parametrize("fanin", [0, 2, 3, 32])
-def test_hub_combine_tree(F, option, fanin):
-    """Hub rows of 90 and 300 neighbours cut into 2-neighbour chunks: up to 8 levels of the fan-in tree."""
+def test_hub_combine_tree(F, option, fanin, merge):
+    """Hub rows of 90 and 300 neighbours cut into 2-neighbour chunks: up to 8 levels of the fan-in tree, all in one
+    launch (merge_finalize = 1: upper nodes wait for the sums they add) or one launch per level."""
     n, dim, batch = 320, 128, 128
     rowptr, colids = random_graph(n, 4, seed=21, hubs=((1, 90), (200, 300)))
     rng = np.random.default_rng(2)
     X0 = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
     eng = F.Engine(rowptr, colids, dim)
     eng.set_param("hub_chunk", 2)
+    eng.set_param("merge_finalize", merge)
     eng.set_param("hub_fanin", fanin)
     O.set_fanin(fanin)
     try:
@@ -133,6 +136,27 @@ def test_hub_combine_tree(F, option, fanin):
     finally:
         O.set_fanin(32)
         eng.close()
+
+
+@pytest.mark.parametrize("dim,fanin", [(128, 2), (128, 4), (100, 3), (32, 2)])
+def test_single_launch_combine_tree_under_load(F, dim, fanin):
+    """RMAT-16 cut into 8-neighbour chunks with a tiny fan-in: tens of thousands of tree nodes in up to a dozen levels,
+    every upper node waiting on flags inside ONE launch -- the same bits as one launch per level, epoch after epoch."""
+    from force2vec_amd.graph import rmat_csr
+    rowptr, colids = rmat_csr(16, 16, seed=4)
+    res = []
+    for merge in (1, 0):
+        eng = F.Engine(rowptr, colids, dim)
+        eng.set_param("hub_chunk", 8)
+        eng.set_param("hub_fanin", fanin)
+        eng.set_param("merge_finalize", merge)
+        eng.srand(1)
+        eng.init_embeddings(0)
+        eng.train(5, 3, 16384, 5, 0.02, 0)
+        eng.train(6, 1, 5000, 5, 0.02, 0)
+        res.append(eng.get_embeddings())
+        eng.close()
+    assert np.array_equal(res[0], res[1]) and np.isfinite(res[0]).all()
 
 
 def _csr(n, edges):
