@@ -141,6 +141,10 @@ def main():
     ap.add_argument("--push-fused", choices=["auto", "1", "0"], default="auto",
                     help="push exchange: rows pushed by the step kernels themselves (1), by a kernel behind them (0), or whichever "
                          "is faster on this machine over a few untimed epochs (auto)")
+    ap.add_argument("--settle-ms", type=float, default=40.0,
+                    help="before the W warmup steps: epochs of the same workload until this much time has passed -- after any idle "
+                         "gap the GPU's power controller needs ~15 ms of steady load before epoch times stop moving "
+                         "(profiles/r01_idle_effect.txt); 0 = none")
     ap.add_argument("--no-verify", action="store_true", help="N>1: skip the bit-for-bit check of every replica against a single-GPU run")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: self-test of the N>1 plumbing on a one-GPU box (all ranks on device 0, exchange through the host)")
@@ -250,7 +254,21 @@ def main():
         st["device_seconds"] = None  # the sharded loop is timed by the wall clock below
         return st
 
+    def settle(batch):
+        """Same workload, untimed, until the device has been under steady load for --settle-ms."""
+        if args.settle_ms <= 0:
+            return 0
+        run_epochs(2, batch)  # launch plans are built here, on the host: not load yet
+        eng.synchronize()
+        done, t0 = 2, time.perf_counter()
+        while max_over_ranks((time.perf_counter() - t0) * 1e3) < args.settle_ms and done < 1000:
+            run_epochs(4, batch)
+            eng.synchronize()
+            done += 4
+        return done
+
     def timed(k, w, batch):
+        state["settle_epochs"] = settle(batch)
         if w > 0:
             run_epochs(w, batch)
         barrier()
@@ -304,6 +322,7 @@ def main():
         if state["exchange"] == "push":
             tune_push()
     dt, st = timed(args.steps, args.warmup, args.batch)
+    main_settle = state["settle_epochs"]
     verified = None
     if use_dist and not args.no_verify:
         verified = verify(schedule)
@@ -327,6 +346,7 @@ def main():
         "config": {"workload": "RMAT scale-%d edge-factor 16 (n=%d, nnz=%d directed CSR nonzeros), option %d, D=%d, ns=5, lr=0.02, batch=%d; step = 1 epoch"
                    % (args.scale, n, nnz, args.option, args.dim, args.batch),
                    "batch": args.batch, "hub_chunk": eng.get_param("hub_chunk"),
+                   "settle": "%d untimed epochs of the same workload (>= %g ms) before the %d warmup steps" % (main_settle, args.settle_ms, args.warmup),
                    "parallelism": "1 GPU" if not use_dist else "minibatch rows sharded over %d GPUs, replicated graph+matrix, %s" % (world, {
                        "push": "new rows pushed over xGMI into the HBM of the peers that read them (HIP kernel + device-side flag barrier)",
                        "allgather": "%s all-gather of the new rows" % ("RCCL" if args.dist_backend == "nccl" else "gloo (host-bounce self-test)"),
@@ -360,8 +380,11 @@ def main():
             except Exception:
                 pass
         res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": traffic, "kernel": ("f2v::qstep_kernel<%d, %d, %d, %d>" % (5 if args.option in (5, 8, 11) else 6, min(16, args.dim // 4), max(1, args.dim // 64), 4 if args.dim >= 128 else 8)) if args.dim in (16, 32, 64, 128, 256) else "f2v::step_kernel", "algorithmic_bytes_per_launch": per_launch,
-                           "avg_launch_us": t_launch * 1e6, "launches": st["step_launches"]}
+                           "traffic": traffic, "kernel": ("f2v::qstep_kernel<%d, %d, %d, %d, %s>" % (5 if args.option in (5, 8, 11) else 6, min(16, args.dim // 4), max(1, args.dim // 64), 4 if args.dim >= 128 else 8, "true" if (use_dist and world > 1 and state["exchange"] == "push" and eng.get_param("push_fused")) else "false")) if args.dim in (16, 32, 64, 128, 256) else "f2v::step_kernel", "algorithmic_bytes_per_launch": per_launch,
+                           "avg_launch_us": t_launch * 1e6, "launches": st["step_launches"],
+                           # frac counts ALGORITHMIC bytes, so XCD-L2 hits on hub rows can push it past 1; what actually crossed
+                           # the fabric (PMC) over the same time is the honest HBM utilisation
+                           "hbm_frac_from_traffic": (traffic / t_launch * 1e-9 / HBM_PEAK_GBS) if traffic else None}
     if rank == 0 and not use_dist:
         extra = {}
         for b in [int(x) for x in args.extra_batches.split(",") if x]:
