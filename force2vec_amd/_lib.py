@@ -56,6 +56,7 @@ SIGNATURES = {
     "f2v_push_selftest": (C.c_int, [C.c_void_p]),
     "f2v_push_detach": (C.c_int, [C.c_void_p]),
     "f2v_train_sharded": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_int, C.POINTER(C.c_double)]),
+    "f2v_shard_bounds": (C.c_int, [u32p, C.c_uint32, C.c_uint32, C.c_uint32, u32p]),
     "f2v_push_masks": (C.c_int, [u32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32, u32p, C.c_uint64, u32p]),
     "f2v_push_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "f2v_read_mtx": (C.c_int, [C.c_char_p, u32p, C.POINTER(C.c_uint64), C.POINTER(u32p), C.POINTER(u32p)]),

@@ -502,11 +502,19 @@ void generate_walks_host(f2v_ctx *c, std::vector<uint32_t> &walks) {
 }
 
 // ---- push exchange helpers (include/f2v.h) ---------------------------------------------------------------
-// slice of rank r of minibatch [lo,hi): contiguous, equal (the same rule as force2vec_amd/dist.py shard_bounds)
-void shard_of(uint32_t lo, uint32_t hi, uint32_t rank, uint32_t world, uint32_t *my_lo, uint32_t *my_hi) {
-    const uint32_t per = (hi - lo + world - 1) / world;
-    *my_lo = (uint32_t)std::min<uint64_t>((uint64_t)lo + (uint64_t)rank * per, hi);
-    *my_hi = (uint32_t)std::min<uint64_t>((uint64_t)*my_lo + per, hi);
+// slice of rank r of minibatch [lo,hi): contiguous; work-balanced over the CSR (f2v_shard_bounds), equal row counts
+// for the walk-based option 7 (every row has five pairs)
+void shard_of(const f2v_ctx *c, bool walk, uint32_t lo, uint32_t hi, uint32_t rank, uint32_t world, uint32_t *my_lo, uint32_t *my_hi) {
+    if (walk) {
+        const uint32_t per = (hi - lo + world - 1) / world;
+        *my_lo = (uint32_t)std::min<uint64_t>((uint64_t)lo + (uint64_t)rank * per, hi);
+        *my_hi = (uint32_t)std::min<uint64_t>((uint64_t)*my_lo + per, hi);
+        return;
+    }
+    uint32_t bounds[kMaxRanks + 1];
+    (void)f2v_shard_bounds(c->rowptr.data(), lo, hi, world, bounds);
+    *my_lo = bounds[rank];
+    *my_hi = bounds[rank + 1];
 }
 
 // copy my rows [row_lo,row_hi) of matrix `which` into the same matrix of the peers that read them
@@ -592,7 +600,7 @@ int prepare_masks(f2v_ctx *c, uint32_t batch, const std::vector<uint32_t> &ids) 
         P.pushed_per_epoch = 0;
         for (uint32_t b0 = 0; b0 < c->n; b0 += batch) {
             uint32_t lo, hi;
-            shard_of(b0, (uint32_t)std::min<uint64_t>((uint64_t)b0 + batch, c->n), P.rank, P.world, &lo, &hi);
+            shard_of(c, false, b0, (uint32_t)std::min<uint64_t>((uint64_t)b0 + batch, c->n), P.rank, P.world, &lo, &hi);
             for (uint32_t v = lo; v < hi; v++) P.pushed_per_epoch += (uint64_t)__builtin_popcount(P.base_masks[v]);
         }
     }
@@ -1094,7 +1102,7 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
     }
     for (uint32_t b = 0; b < nb; b++) {  // all launch plans up-front: one upload, no syncs inside the timed loop
         uint32_t lo = b * batch, hi = (uint32_t)std::min<uint64_t>((uint64_t)b * batch + batch, n);
-        if (sharded) shard_of(lo, hi, c->push.rank, c->push.world, &lo, &hi);
+        if (sharded) shard_of(c, math == 7, lo, hi, c->push.rank, c->push.world, &lo, &hi);
         (void)plan_for(c, lo, hi, math == 7);
     }
     if ((rc = upload_plans(c)) != F2V_OK) return rc;
@@ -1199,7 +1207,7 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
             const uint32_t lo = b * batch;
             const uint32_t hi = (uint32_t)std::min<uint64_t>((uint64_t)lo + batch, n);
             uint32_t my_lo = lo, my_hi = hi;
-            if (sharded) shard_of(lo, hi, c->push.rank, c->push.world, &my_lo, &my_hi);
+            if (sharded) shard_of(c, math == 7, lo, hi, c->push.rank, c->push.world, &my_lo, &my_hi);
             if ((rc = launch_step(c, math, lo, hi, my_lo, my_hi, d_epoch_ids + (size_t)b * stride, ns, lr, bs_mode, exchanging && c->push.fused, d_masks)) != F2V_OK) return rc;
             if (exchanging) {
                 if (!c->push.fused && (rc = launch_push(c, c->cur ^ 1, d_masks, my_lo, my_hi)) != F2V_OK) return rc;
@@ -1216,7 +1224,7 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
         for (uint32_t b = 0; b < nb; b++) {
             const uint32_t lo = b * batch;
             uint32_t my_lo, my_hi;
-            shard_of(lo, (uint32_t)std::min<uint64_t>((uint64_t)lo + batch, n), c->push.rank, c->push.world, &my_lo, &my_hi);
+            shard_of(c, math == 7, lo, (uint32_t)std::min<uint64_t>((uint64_t)lo + batch, n), c->push.rank, c->push.world, &my_lo, &my_hi);
             if ((rc = launch_push(c, c->cur, nullptr, my_lo, my_hi)) != F2V_OK) return rc;
         }
         if ((rc = launch_barrier(c)) != F2V_OK) return rc;

@@ -196,6 +196,14 @@ class Engine:
         return {k: getattr(s, k) for k, _ in s._fields_}
 
 
+def shard_bounds_balanced(rowptr, lo, hi, world):
+    """f2v_shard_bounds (host only): uint32[world+1], slice r = rows [b[r], b[r+1]) of minibatch [lo,hi), balanced by degree + 4."""
+    rp = np.ascontiguousarray(rowptr, dtype=np.uint32)
+    out = np.zeros(world + 1, dtype=np.uint32)
+    check(_lib.lib().f2v_shard_bounds(_u32(rp), lo, hi, world, _u32(out)))
+    return out
+
+
 def push_masks(rowptr, colids, batch, world, sample_ids=()):
     """f2v_push_masks (host only): uint32[n], bit r = rank r reads the row without owning it."""
     rp = np.ascontiguousarray(rowptr, dtype=np.uint32)

@@ -156,9 +156,13 @@ int f2v_push_selftest(f2v_handle h);
 int f2v_push_detach(f2v_handle h);
 int f2v_train_sharded(f2v_handle h, int option, uint32_t iters, uint32_t batch, uint32_t ns, float lr, int bs_mode,
                       double *seconds_out);
+/* Host-only: the slices f2v_train_sharded cuts minibatch [lo,hi) into: bounds_out[0..world], slice r = rows
+ * [bounds_out[r], bounds_out[r+1]), contiguous and balanced by work (weight of a row = its degree + 4), not by
+ * row count.  (Option 7 uses equal row counts: its rows all have five pairs.) */
+int f2v_shard_bounds(const uint32_t *rowptr, uint32_t lo, uint32_t hi, uint32_t world, uint32_t *bounds_out);
 /* Host-only: masks_out[v] = bit r set when rank r READS row v without owning it -- v is a CSR neighbour of a
- * row in one of r's slices (slice r of minibatch [lo,hi) = rows lo + r*ceil((hi-lo)/world) ...), or one of
- * `sample_ids` (read by every row of a minibatch, hence by every rank). */
+ * row in one of r's slices (f2v_shard_bounds of every minibatch), or one of `sample_ids` (read by every row of a
+ * minibatch, hence by every rank). */
 int f2v_push_masks(const uint32_t *rowptr, const uint32_t *colids, uint32_t n, uint32_t batch, uint32_t world,
                    const uint32_t *sample_ids, uint64_t n_ids, uint32_t *masks_out);
 /* Rows pushed to peers / rows a full all-gather would have sent (per peer copies), since the last f2v_train_sharded began. */

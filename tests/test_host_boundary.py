@@ -197,12 +197,34 @@ def test_parallel_init_equals_the_serial_rand_stream():
             L.f2v_rng_destroy(g)
 
 
+def test_shard_bounds_balance_work_not_rows():
+    """f2v_shard_bounds: contiguous slices covering the minibatch, each within one row's weight of an equal share of
+    sum(degree + 4); a hub heavier than a whole share gets a slice of its own (its neighbours' slices may be empty)."""
+    from force2vec_amd.engine import shard_bounds_balanced
+    from force2vec_amd.graph import rmat_csr
+    rp, _ = rmat_csr(14, 16, 2)
+    n = len(rp) - 1
+    deg = np.diff(rp.astype(np.int64))
+    w = deg + 4
+    for lo, hi, world in [(0, n, 8), (1000, 9192, 4), (5, 6, 3), (7, 7, 2), (n - 100, n, 5), (0, 4096, 1)]:
+        b = shard_bounds_balanced(rp, lo, hi, world).astype(np.int64)
+        assert b[0] == lo and b[-1] == hi and np.all(np.diff(b) >= 0)
+        total = w[lo:hi].sum()
+        for r in range(world):
+            mine = w[b[r]:b[r + 1]].sum()
+            heaviest = w[b[r]:b[r + 1]].max() if b[r + 1] > b[r] else 0
+            assert mine <= total / world + heaviest + 1, (lo, hi, world, r)
+    # a graph whose first row is one enormous hub: the hub is a slice, the rest is shared out behind it
+    rp2 = np.concatenate([[0, 10000], 10000 + 3 * np.arange(1, 64)]).astype(np.uint32)
+    b = shard_bounds_balanced(rp2, 0, 64, 4)
+    assert b[1] == 1 and list(b) == sorted(b) and b[-1] == 64
+
+
 def test_push_masks_name_exactly_the_ranks_that_read_a_row():
     """f2v_push_masks against a brute-force restatement: rank r reads v iff v is a CSR neighbour of a row in one of
-    r's minibatch slices, or v is sampled; the owner's own bit is never set."""
-    from force2vec_amd.engine import push_masks
+    r's minibatch slices (f2v_shard_bounds), or v is sampled; the owner's own bit is never set."""
+    from force2vec_amd.engine import push_masks, shard_bounds_balanced
     from force2vec_amd.graph import rmat_csr
-    from force2vec_amd.dist import shard_bounds
     rp, ci = rmat_csr(11, 8, 3)
     n = len(rp) - 1
     for batch, world in [(256, 2), (300, 3), (4096, 8), (100, 5)]:
@@ -211,9 +233,9 @@ def test_push_masks_name_exactly_the_ranks_that_read_a_row():
         owner = np.zeros(n, dtype=np.int64)
         for lo in range(0, n, batch):
             hi = min(lo + batch, n)
+            b = shard_bounds_balanced(rp, lo, hi, world)
             for r in range(world):
-                _, a, b = shard_bounds(lo, hi, r, world)
-                owner[a:b] = r
+                owner[b[r]:b[r + 1]] = r
         want = np.zeros(n, dtype=np.uint32)
         for u in range(n):
             want[ci[rp[u]:rp[u + 1]]] |= np.uint32(1 << owner[u])
