@@ -35,7 +35,8 @@
 // Load balance (the GPU counterpart of option 11's nnz-balanced partition,
 // sample/algorithms.cpp:2483-2523): the host cuts every minibatch into work ITEMS -- a whole
 // row, or one `chunk`-neighbour piece of a hub row (degree > chunk) -- sorted longest first.
-// Hub pieces leave partial sums in HBM; hub_finalize_kernel adds them, `fanin` at a time, in chunk order.
+// Hub pieces leave partial sums in HBM; combine-tree nodes add them, `fanin` at a time, in chunk order -- in the
+// sub-wave kernel as extra workgroups at the end of the same grid, so that a minibatch is one launch.
 #ifndef F2V_KERNELS_HIP_H_
 #define F2V_KERNELS_HIP_H_
 

@@ -56,11 +56,16 @@ int f2v_set_embeddings(f2v_handle h, const float *x);
 int f2v_get_embeddings(f2v_handle h, float *x_out);
 
 /* Tunables.  "hub_chunk": neighbours per work item before a row is split (0 = never split: the
- * reference's summation order for every row; unset = chosen from the batch size by f2v_train, or
- * by setting "hub_chunk_for_batch" = B); "hub_fanin": fan-in of the tree that adds a split row's
- * partial sums (0 = one sequential pass); "quarter_wave": 0 selects the one-item-per-wavefront
+ * reference's summation order for every row; unset = chosen by f2v_train from the rows one launch covers
+ * -- the batch, or a rank's slice of it in f2v_train_sharded -- or by setting "hub_chunk_for_batch" = B;
+ * the chunk is part of the summation order, so pin it where bits must not depend on the number of GPUs);
+ * "hub_fanin": fan-in of the tree that adds a split row's partial sums (0 = one sequential pass);
+ * "merge_finalize" (default 1): the trees' nodes run in the step kernel's own grid (one launch per
+ * minibatch), 0 = one launch per tree level; "quarter_wave": 0 selects the one-item-per-wavefront
  * kernel for every D; "waves_per_block"; "rows_in_flight" (4|8); "use_graph" = 1 makes f2v_train replay a
  * captured hipGraph per epoch instead of launching eagerly (same results; measured no faster).
+ * Sharded runs: "push_fused" (default 1: the step kernels push their rows themselves, 0: a kernel behind
+ * them does), "push_timeout_ms".
  * "fast_rng" = 1 selects the NON-PARITY fast mode: initial embeddings and the option-7
  * walks are generated on the device by a counter-based RNG (same distributions, different numbers than
  * the reference's libc rand() stream); negative-sample ids still come from the handle's rand() stream.
