@@ -184,7 +184,11 @@ def main():
                 local_rank = 0  # the launcher gave every rank its own single visible device
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            host_group = dist.new_group(backend="gloo") if world > 1 else None  # handle exchange of the push path, insurance path of NcclStageComm
+            try:  # handle exchange of the push path, insurance path of NcclStageComm
+                host_group = dist.new_group(backend="gloo") if world > 1 else None
+            except Exception as exn:  # the RCCL group carries the (pickled) handles just as well
+                log("bench[rank %d]: no gloo group (%r); using the RCCL group for the handle exchange" % (rank, exn))
+                host_group = None
 
     if use_dist and world > 1:
         # one rank generates (or finds) the cached graph, the others read the cache
