@@ -35,8 +35,17 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+T0 = time.time()
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def note(rank, msg):
+    """Progress on stderr (every rank: a stuck rank shows where it stopped)."""
+    if os.environ.get("F2V_BENCH_QUIET") != "1":
+        print("bench[rank %d +%.1fs]: %s" % (rank, time.time() - T0, msg), file=sys.stderr, flush=True)
 
 
 def load_graph(scale, edge_factor, seed):
@@ -197,6 +206,7 @@ def main():
         dist.barrier(group=host_group) if host_group is not None else dist.barrier()
     rowptr, colids = load_graph(args.scale, 16, 1)
     n, nnz = len(rowptr) - 1, len(colids)
+    note(rank, "graph ready: n=%d nnz=%d" % (n, nnz))
     eng = F.Engine(rowptr, colids, args.dim, device=local_rank)
     if args.hub_chunk >= 0:
         eng.set_param("hub_chunk", args.hub_chunk)
@@ -205,6 +215,7 @@ def main():
         eng.set_param(k, int(v))
     eng.srand(1)
     eng.init_embeddings(F._lib.INIT_SYMMETRIC if args.option in (5, 8, 11) else F._lib.INIT_UNIT)
+    note(rank, "engine ready, embeddings initialised")
 
     def barrier():
         eng.synchronize()
@@ -226,6 +237,7 @@ def main():
             comm = fdist.PushExchange(dist, rank, world, group=host_group)
             try:
                 comm.attach(eng)
+                note(rank, "push exchange attached, self-test passed")
             except Exception as exn:  # raised on every rank alike (the ranks agree inside attach)
                 state["note"] = "push exchange unavailable (%s): fell back to the RCCL all-gather" % (str(exn)[:200],)
                 log("bench[rank %d]: %s" % (rank, state["note"]))
@@ -295,6 +307,7 @@ def main():
             eng.set_param("push_fused", int(args.push_fused))
             return
         run_epochs(1, args.batch)  # launch plans and reader masks exist from here on
+        note(rank, "first sharded epoch done")
         took = {}
         for fused in (1, 0):
             eng.set_param("push_fused", fused)
@@ -305,6 +318,7 @@ def main():
             took[fused] = max_over_ranks(time.perf_counter() - t0) / 3
         best = 1 if took[1] <= took[0] else 0
         eng.set_param("push_fused", best)
+        note(rank, "push variants timed: fused %.3f ms, separate kernel %.3f ms per epoch" % (took[1] * 1e3, took[0] * 1e3))
         state["tuned"] = {"push_fused": best, "ms_per_epoch_fused": took[1] * 1e3, "ms_per_epoch_separate_kernel": took[0] * 1e3}
 
     def verify(schedule):
@@ -327,9 +341,11 @@ def main():
             tune_push()
     dt, st = timed(args.steps, args.warmup, args.batch)
     main_settle = state["settle_epochs"]
+    note(rank, "timed region done: %.3f ms per epoch" % (dt / args.steps * 1e3))
     verified = None
     if use_dist and not args.no_verify:
         verified = verify(schedule)
+        note(rank, "replica compared with a single-GPU run of the same %d epochs: %s" % (sum(k for k, _ in schedule), "identical" if verified else "DIFFERENT"))
         if not verified and state["exchange"] == "push":
             # never report a number for wrong results: redo the whole measurement over the RCCL all-gather
             state["note"] = "push exchange gave a replica that differs from the single-GPU run: measured again over the RCCL all-gather"

@@ -48,9 +48,10 @@ struct Plan {
 
 // what a rank hands its peers (f2v_push_export): F2V_PUSH_EXPORT_BYTES bytes
 struct PushExport {
-    hipIpcMemHandle_t x[2], flags;
+    hipIpcMemHandle_t x[2], flags;  // landing-buffer mode: x[0] is the landing buffer, x[1] unused
     uint32_t magic, n, D, cur;
-    char reserved[F2V_PUSH_EXPORT_BYTES - 3 * sizeof(hipIpcMemHandle_t) - 16];
+    uint32_t landing, landing_cap;
+    char reserved[F2V_PUSH_EXPORT_BYTES - 3 * sizeof(hipIpcMemHandle_t) - 24];
 };
 static_assert(sizeof(PushExport) == F2V_PUSH_EXPORT_BYTES, "export blob layout");
 static_assert(kMaxRanks == F2V_PUSH_MAX_RANKS, "rank limit");
@@ -110,6 +111,14 @@ struct f2v_ctx {
         uint32_t *d_masks = nullptr, *d_patch = nullptr;
         size_t patch_cap = 0;
         uint64_t pushed_per_epoch = 0, rows_pushed = 0, rows_allgather = 0;
+        // Landing-buffer mode: hipIpcOpenMemHandle never returns for an allocation of 2 GiB or more (ROCm 7.x), so a
+        // matrix that large cannot be mapped into the peers.  The peers then push a minibatch's rows into a small
+        // mapped buffer (two halves, alternating per exchange) and unpack_rows_kernel moves them into the matrix
+        // behind the barrier.
+        bool landing = false, force_landing = false;
+        float *landing_buf = nullptr, *peer_landing[kMaxRanks] = {};
+        uint32_t landing_cap = 0;  // rows per half
+        uint32_t round = 0;        // exchanges done: (round & 1) is the half in use
     } push;
 };
 
@@ -321,6 +330,8 @@ int math_of_option(int option) {
 }
 
 // Launch one minibatch step (+ hub finalisation) on the handle's stream.  d_ids: device sample ids.
+void fill_targets(const f2v_ctx *c, PushTargets &t, int which, uint32_t batch_lo, const uint32_t *d_masks);
+
 // push_masks / push: a sharded run's step -- the kernels also store every finished row into the second matrix of
 // the peers that read it (push_masks == nullptr: of every peer).
 int launch_step(f2v_ctx *c, int math, uint32_t batch_lo, uint32_t batch_hi, uint32_t row_lo, uint32_t row_hi,
@@ -351,12 +362,7 @@ int launch_step(f2v_ctx *c, int math, uint32_t batch_lo, uint32_t batch_hi, uint
     a.bs_mode = bs_mode ? 1u : 0u;
     a.lr = lr;
     push = push && c->push.attached && c->push.world > 1;
-    if (push) {
-        for (uint32_t r = 0; r < c->push.world; r++) a.push.peer[r] = c->push.peer_X[c->cur ^ 1][r];
-        a.push.masks = push_masks;
-        a.push.self = c->push.rank;
-        a.push.world = c->push.world;
-    }
+    if (push) fill_targets(c, a.push, c->cur ^ 1, batch_lo, push_masks);
 
     const uint32_t wpb = (uint32_t)c->waves_per_block;
     // sub-wave layout when D is 16, 32, 64, 128 or 256: 16, 8 or 4 work items per wavefront
@@ -517,18 +523,27 @@ void shard_of(const f2v_ctx *c, bool walk, uint32_t lo, uint32_t hi, uint32_t ra
     *my_hi = bounds[rank + 1];
 }
 
-// copy my rows [row_lo,row_hi) of matrix `which` into the same matrix of the peers that read them
-int launch_push(f2v_ctx *c, int which, const uint32_t *d_masks, uint32_t row_lo, uint32_t row_hi) {
+// where the peers receive rows of the minibatch that starts at `batch_lo`: their copy of matrix `which`, or the half of
+// their landing buffer this exchange uses
+void fill_targets(const f2v_ctx *c, PushTargets &t, int which, uint32_t batch_lo, const uint32_t *d_masks) {
+    const auto &P = c->push;
+    for (uint32_t r = 0; r < P.world; r++)
+        t.peer[r] = P.landing ? P.peer_landing[r] + (size_t)(P.round & 1u) * P.landing_cap * c->D : P.peer_X[which][r];
+    t.masks = d_masks;
+    t.self = P.rank;
+    t.world = P.world;
+    t.row_base = P.landing ? batch_lo : 0u;
+}
+
+// copy my rows [row_lo,row_hi) of local matrix `which` to the peers that read them
+int launch_push(f2v_ctx *c, int which, const uint32_t *d_masks, uint32_t batch_lo, uint32_t row_lo, uint32_t row_hi) {
     if (c->push.world < 2 || row_hi <= row_lo) return F2V_OK;
     PushArgs a{};
     a.src = c->d_X[which];
-    for (uint32_t r = 0; r < c->push.world; r++) a.peer[r] = c->push.peer_X[which][r];
-    a.masks = d_masks;
+    fill_targets(c, a.to, which, batch_lo, d_masks);
     a.row_lo = row_lo;
     a.rows = row_hi - row_lo;
     a.D = c->D;
-    a.self = c->push.rank;
-    a.world = c->push.world;
     const uint32_t wpb = 4;
     const uint32_t blocks = std::min<uint32_t>((a.rows + wpb - 1) / wpb, 2048u);
     int rc = dispatch_layout(c, [&](auto V, auto E) {
@@ -536,6 +551,36 @@ int launch_push(f2v_ctx *c, int which, const uint32_t *d_masks, uint32_t row_lo,
     });
     if (rc != F2V_OK) return rc;
     HIPC(hipGetLastError());
+    return F2V_OK;
+}
+
+int launch_barrier(f2v_ctx *c);
+
+// End of one exchange: the flag barrier and, in landing-buffer mode, the move of what the peers sent for minibatch
+// [lo,hi) (this rank computed [my_lo,my_hi)) from the landing buffer into matrix `which`.
+int finish_exchange(f2v_ctx *c, int which, const uint32_t *d_masks, uint32_t lo, uint32_t hi, uint32_t my_lo, uint32_t my_hi) {
+    int rc = launch_barrier(c);
+    if (rc != F2V_OK) return rc;
+    auto &P = c->push;
+    if (P.world < 2 || !P.landing) return F2V_OK;
+    UnpackArgs u{};
+    u.landing = P.landing_buf + (size_t)(P.round & 1u) * P.landing_cap * c->D;
+    u.X = c->d_X[which];
+    u.masks = d_masks;
+    u.lo = lo;
+    u.rows = hi - lo;
+    u.my_lo = my_lo;
+    u.my_hi = my_hi;
+    u.D = c->D;
+    u.self = P.rank;
+    const uint32_t wpb = 4;
+    const uint32_t blocks = std::min<uint32_t>((u.rows + wpb - 1) / wpb, 2048u);
+    rc = dispatch_layout(c, [&](auto V, auto E) {
+        hipLaunchKernelGGL((unpack_rows_kernel<decltype(V)::value, decltype(E)::value>), dim3(blocks), dim3(64 * wpb), 0, c->stream, u);
+    });
+    if (rc != F2V_OK) return rc;
+    HIPC(hipGetLastError());
+    P.round++;
     return F2V_OK;
 }
 
@@ -571,11 +616,12 @@ int push_detach(f2v_ctx *c) {
             for (int k = 0; k < 2; k++)
                 if (c->push.peer_X[k][r]) (void)hipIpcCloseMemHandle(c->push.peer_X[k][r]);
             if (c->push.peer_flags[r]) (void)hipIpcCloseMemHandle(c->push.peer_flags[r]);
+            if (c->push.peer_landing[r]) (void)hipIpcCloseMemHandle(c->push.peer_landing[r]);
         }
     }
     for (int k = 0; k < 2; k++)
         for (int r = 0; r < kMaxRanks; r++) c->push.peer_X[k][r] = nullptr;
-    for (int r = 0; r < kMaxRanks; r++) c->push.peer_flags[r] = nullptr;
+    for (int r = 0; r < kMaxRanks; r++) { c->push.peer_flags[r] = nullptr; c->push.peer_landing[r] = nullptr; }
     c->push.attached = false;
     c->push.local = false;
     c->push.rank = 0;
@@ -690,7 +736,7 @@ int f2v_destroy(f2v_handle c) {
     (void)hipSetDevice(c->device);
     (void)push_detach(c);
     void *ptrs[] = {c->d_rowptr, c->d_colids, c->d_walks, c->d_ids, c->d_X[0], c->d_X[1],
-                    c->d_partials, c->d_table, c->d_items, c->d_hubs, c->d_ready, c->d_kerr, c->push.flags, c->push.d_err, c->push.d_masks, c->push.d_patch};
+                    c->d_partials, c->d_table, c->d_items, c->d_hubs, c->d_ready, c->d_kerr, c->push.flags, c->push.d_err, c->push.d_masks, c->push.d_patch, c->push.landing_buf};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -831,6 +877,10 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
         c->merge_fin = value != 0;
         return F2V_OK;
     }
+    if (!strcmp(name, "push_landing")) {  // takes effect at the next f2v_push_export
+        c->push.force_landing = value != 0;
+        return F2V_OK;
+    }
     if (!strcmp(name, "push_timeout_ms")) {
         if (value < 1 || value > 600000) return fail(F2V_EINVAL, "push_timeout_ms must be 1..600000");
         c->push.timeout_ms = value;
@@ -856,6 +906,7 @@ int f2v_get_param(f2v_handle c, const char *name, int64_t *out) {
     if (!strcmp(name, "push_timeout_ms")) { *out = c->push.timeout_ms; return F2V_OK; }
     if (!strcmp(name, "push_fused")) { *out = c->push.fused ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "merge_finalize")) { *out = c->merge_fin ? 1 : 0; return F2V_OK; }
+    if (!strcmp(name, "push_landing")) { *out = (c->push.attached || c->push.exported) ? (c->push.landing ? 1 : 0) : (c->push.force_landing ? 1 : 0); return F2V_OK; }
     if (!strcmp(name, "push_world")) { *out = c->push.attached ? c->push.world : 0; return F2V_OK; }
     if (!strcmp(name, "push_rank")) { *out = c->push.rank; return F2V_OK; }
     if (!strcmp(name, "dim")) { *out = c->D; return F2V_OK; }
@@ -1137,6 +1188,8 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
     // sharded: who reads which row is static when the neighbours are the CSR's and the run's sample ids are known
     // up-front; otherwise (option 7's walks, -bs 1's per-row sample windows) every new row goes to every peer
     const bool exchanging = sharded && c->push.world > 1;
+    if (exchanging && c->push.landing && std::min(batch, n) > c->push.landing_cap)
+        return fail(F2V_EINVAL, "f2v_train_sharded: a minibatch of %u rows does not fit the landing buffer (%u rows; matrices of 2 GiB and more are exchanged through it)", std::min(batch, n), c->push.landing_cap);
     const bool need_based = exchanging && math != 7 && !bs_mode && all_upfront;
     const uint32_t *d_masks = nullptr;
     if (need_based) {
@@ -1210,8 +1263,8 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
             if (sharded) shard_of(c, math == 7, lo, hi, c->push.rank, c->push.world, &my_lo, &my_hi);
             if ((rc = launch_step(c, math, lo, hi, my_lo, my_hi, d_epoch_ids + (size_t)b * stride, ns, lr, bs_mode, exchanging && c->push.fused, d_masks)) != F2V_OK) return rc;
             if (exchanging) {
-                if (!c->push.fused && (rc = launch_push(c, c->cur ^ 1, d_masks, my_lo, my_hi)) != F2V_OK) return rc;
-                if ((rc = launch_barrier(c)) != F2V_OK) return rc;
+                if (!c->push.fused && (rc = launch_push(c, c->cur ^ 1, d_masks, lo, my_lo, my_hi)) != F2V_OK) return rc;
+                if ((rc = finish_exchange(c, c->cur ^ 1, d_masks, lo, hi, my_lo, my_hi)) != F2V_OK) return rc;
                 c->push.rows_allgather += (uint64_t)(my_hi - my_lo) * (c->push.world - 1);
             }
         }
@@ -1222,12 +1275,14 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
     if (need_based && iters > 0) {
         // replicas are complete only in the rows their rank reads: one full exchange makes them whole
         for (uint32_t b = 0; b < nb; b++) {
-            const uint32_t lo = b * batch;
+            const uint32_t lo = b * batch, hi = (uint32_t)std::min<uint64_t>((uint64_t)lo + batch, n);
             uint32_t my_lo, my_hi;
-            shard_of(c, math == 7, lo, (uint32_t)std::min<uint64_t>((uint64_t)lo + batch, n), c->push.rank, c->push.world, &my_lo, &my_hi);
-            if ((rc = launch_push(c, c->cur, nullptr, my_lo, my_hi)) != F2V_OK) return rc;
+            shard_of(c, math == 7, lo, hi, c->push.rank, c->push.world, &my_lo, &my_hi);
+            if ((rc = launch_push(c, c->cur, nullptr, lo, my_lo, my_hi)) != F2V_OK) return rc;
+            // the landing buffer holds one minibatch: an exchange per minibatch; mapped matrices take them all at once
+            if (c->push.landing && (rc = finish_exchange(c, c->cur, nullptr, lo, hi, my_lo, my_hi)) != F2V_OK) return rc;
         }
-        if ((rc = launch_barrier(c)) != F2V_OK) return rc;
+        if (!c->push.landing && (rc = launch_barrier(c)) != F2V_OK) return rc;
     }
     HIPC(hipEventRecord(ev1, c->stream));
     HIPC(hipEventSynchronize(ev1));
@@ -1262,13 +1317,28 @@ int f2v_push_export(f2v_handle c, void *handles_out) {
     HIPC(hipMemset(c->push.d_err, 0, 64));
     HIPC(hipDeviceSynchronize());
     c->push.seq = 0;
+    c->push.round = 0;
     PushExport e{};
-    for (int k = 0; k < 2; k++) HIPC(hipIpcGetMemHandle(&e.x[k], c->d_X[k]));
+    const size_t matrix_bytes = ((size_t)c->n + kPadRows) * c->D * sizeof(float);
+    c->push.landing = c->push.force_landing || matrix_bytes >= (size_t)0x7FF00000;  // 2 GiB and more cannot be mapped (see Push)
+    if (c->push.landing) {
+        // two halves of at most 512 MiB; room for the self-test's `world` pattern rows in any case
+        const size_t per_row = (size_t)c->D * sizeof(float);
+        c->push.landing_cap = (uint32_t)std::max<size_t>(std::min<size_t>(((size_t)512 << 20) / per_row, (size_t)c->n + kPadRows), 64);
+        if (c->push.landing_buf) (void)hipFree(c->push.landing_buf);
+        c->push.landing_buf = nullptr;
+        HIPC(hipMalloc((void **)&c->push.landing_buf, 2 * (size_t)c->push.landing_cap * per_row));
+        HIPC(hipIpcGetMemHandle(&e.x[0], c->push.landing_buf));
+    } else {
+        for (int k = 0; k < 2; k++) HIPC(hipIpcGetMemHandle(&e.x[k], c->d_X[k]));
+    }
     HIPC(hipIpcGetMemHandle(&e.flags, c->push.flags));
     e.magic = kPushMagic;
     e.n = c->n;
     e.D = c->D;
     e.cur = (uint32_t)c->cur;
+    e.landing = c->push.landing ? 1u : 0u;
+    e.landing_cap = c->push.landing_cap;
     memcpy(handles_out, &e, sizeof e);
     c->push.exported = true;
     return F2V_OK;
@@ -1287,6 +1357,9 @@ int f2v_push_attach(f2v_handle c, uint32_t rank, uint32_t world, const void *all
         if (e.magic != kPushMagic) return fail(F2V_EINVAL, "f2v_push_attach: export of rank %u is not an export", r);
         if (e.n != c->n || e.D != c->D || e.cur != (uint32_t)c->cur)
             return fail(F2V_ESTATE, "f2v_push_attach: rank %u holds a different engine state (n %u dim %u matrix %u; here %u %u %d)", r, e.n, e.D, e.cur, c->n, c->D, c->cur);
+        if ((e.landing != 0) != c->push.landing || (c->push.landing && e.landing_cap != c->push.landing_cap))
+            return fail(F2V_ESTATE, "f2v_push_attach: rank %u exchanges through %s, this rank through %s (\"push_landing\" must agree)", r,
+                        e.landing ? "a landing buffer" : "mapped matrices", c->push.landing ? "a landing buffer" : "mapped matrices");
     }
     c->push.rank = rank;
     c->push.world = world;
@@ -1295,11 +1368,20 @@ int f2v_push_attach(f2v_handle c, uint32_t rank, uint32_t world, const void *all
         if (r == rank) {
             for (int k = 0; k < 2; k++) c->push.peer_X[k][r] = c->d_X[k];
             c->push.peer_flags[r] = c->push.flags;
+            c->push.peer_landing[r] = c->push.landing_buf;
             continue;
         }
         PushExport e;
         memcpy(&e, all + r, sizeof e);
-        for (int k = 0; k < 2; k++) {
+        if (c->push.landing) {
+            hipError_t he = hipIpcOpenMemHandle((void **)&c->push.peer_landing[r], e.x[0], hipIpcMemLazyEnablePeerAccess);
+            if (he != hipSuccess) {
+                c->push.peer_landing[r] = nullptr;
+                (void)push_detach(c);
+                return fail(F2V_ENODEV, "f2v_push_attach: cannot map the landing buffer of rank %u: %s", r, hipGetErrorString(he));
+            }
+        }
+        for (int k = 0; k < 2 && !c->push.landing; k++) {
             hipError_t he = hipIpcOpenMemHandle((void **)&c->push.peer_X[k][r], e.x[k], hipIpcMemLazyEnablePeerAccess);
             if (he != hipSuccess) {
                 c->push.peer_X[k][r] = nullptr;
@@ -1329,6 +1411,8 @@ int f2v_test_push_attach_local(f2v_handle c, uint32_t rank, uint32_t world, cons
             return fail(F2V_ESTATE, "f2v_test_push_attach_local: peer %u is not an exported engine of the same shape on the same device", r);
         for (int k = 0; k < 2; k++) c->push.peer_X[k][r] = all[r]->d_X[k];
         c->push.peer_flags[r] = all[r]->push.flags;
+        c->push.peer_landing[r] = all[r]->push.landing_buf;
+        if (all[r]->push.landing != c->push.landing) return fail(F2V_ESTATE, "f2v_test_push_attach_local: \"push_landing\" must agree");
     }
     c->push.rank = rank;
     c->push.world = world;
@@ -1361,8 +1445,10 @@ int f2v_push_selftest(f2v_handle c) {
     HIPC(hipMemcpyAsync(c->d_X[which] + (size_t)(c->n + me) * D, row.data(), D * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
     if ((rc = launch_barrier(c)) != F2V_OK) return rc;  // nobody pushes before everybody has laid its pattern down
-    if ((rc = launch_push(c, which, nullptr, c->n + me, c->n + me + 1)) != F2V_OK) return rc;
-    if ((rc = launch_barrier(c)) != F2V_OK) return rc;
+    // as a "minibatch" [n, n+W) of which this rank computed row n+me: lands in the peers' slack rows, or in slot `me` of
+    // their landing buffers, from where the exchange's second half moves it to the slack rows
+    if ((rc = launch_push(c, which, nullptr, c->n, c->n + me, c->n + me + 1)) != F2V_OK) return rc;
+    if ((rc = finish_exchange(c, which, nullptr, c->n, c->n + W, c->n + me, c->n + me + 1)) != F2V_OK) return rc;
     HIPC(hipStreamSynchronize(c->stream));
     if ((rc = check_push_err(c, "f2v_push_selftest")) != F2V_OK) return rc;
     std::vector<float> got((size_t)W * D);

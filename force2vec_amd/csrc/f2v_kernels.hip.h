@@ -70,9 +70,12 @@ constexpr int kMaxRanks = 8;  // multi-GPU push exchange: ranks of one xGMI hive
 // Where a rank's new rows go besides its own second matrix (sharded runs): the same matrix of every peer whose bit
 // is set in the row's reader mask.  world <= 1: nothing is pushed.
 struct PushTargets {
-    float *peer[kMaxRanks];   // second matrix of every rank, mapped through HIP IPC (peer[self] is not written)
+    float *peer[kMaxRanks];   // where row `row_base` lands on every rank (mapped through HIP IPC; peer[self] is not written):
+                              // the second matrix itself (row_base = 0), or -- matrices of 2 GiB and more cannot be mapped --
+                              // a landing buffer holding one minibatch (row_base = first row of the minibatch)
     const uint32_t *masks;    // per vertex: bit r = rank r reads the row; nullptr = every rank does
     uint32_t self, world;
+    uint32_t row_base;
 };
 
 struct StepArgs {
@@ -258,7 +261,7 @@ __device__ __forceinline__ void push_row(const PushTargets &t, uint32_t row, uin
     const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)((t.masks ? t.masks[row] : others) & others));
 #pragma unroll
     for (int q = 0; q < kMaxRanks; ++q) {
-        if (m & (1u << q)) store_row_system<VEC, EXACT>(t.peer[q] + (size_t)row * D, lane, D, in);
+        if (m & (1u << q)) store_row_system<VEC, EXACT>(t.peer[q] + (size_t)(row - t.row_base) * D, lane, D, in);
     }
 }
 
@@ -792,7 +795,7 @@ __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
 #pragma unroll
                 for (int q = 0; q < kMaxRanks; ++q) {
                     if (m & (1u << q)) {
-                        float *dst = a.push.peer[q] + (size_t)row * D + t * 4;
+                        float *dst = a.push.peer[q] + (size_t)(row - a.push.row_base) * D + t * 4;
 #pragma unroll
                         for (int b = 0; b < NB; ++b) store16_system(dst + 4 * LPI * b, v[b]);
                     }
@@ -879,10 +882,9 @@ __global__ __launch_bounds__(256) void commit_kernel(float *X, const float *Xn, 
 
 struct PushArgs {
     const float *src;         // local matrix that holds the new rows
-    float *peer[kMaxRanks];   // that matrix on every rank (peer[self] is not written)
-    const uint32_t *masks;    // per vertex: bit r = rank r reads the row; nullptr = every rank does
+    PushTargets to;
     uint32_t row_lo, rows;    // this rank's rows of the minibatch
-    uint32_t D, self, world;
+    uint32_t D;
 };
 
 template <int VEC, bool EXACT>
@@ -890,19 +892,38 @@ __global__ __launch_bounds__(256) void push_rows_kernel(const PushArgs p) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wpb = blockDim.x >> 6;
     const uint32_t total = gridDim.x * wpb;
-    const uint32_t others = ((p.world >= 32u ? 0xFFFFFFFFu : ((1u << p.world) - 1u))) & ~(1u << p.self);
     for (uint32_t r = blockIdx.x * wpb + (threadIdx.x >> 6); r < p.rows; r += total) {
         const uint32_t row = p.row_lo + r;
-        const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)((p.masks ? p.masks[row] : others) & others));
-        if (!m) continue;
         float t[VEC];
         load_row<VEC, EXACT>(p.src + (size_t)row * p.D, lane, p.D, t);
-#pragma unroll
-        for (int q = 0; q < kMaxRanks; ++q) {
-            if (m & (1u << q)) store_row_system<VEC, EXACT>(p.peer[q] + (size_t)row * p.D, lane, p.D, t);
-        }
+        push_row<VEC, EXACT>(p.to, row, lane, p.D, t);
     }
     __builtin_amdgcn_s_waitcnt(0);  // this wave's stores have been acknowledged by the peers' memory before it ends
+}
+
+// Landing-buffer mode, after the barrier: rows of minibatch [lo, lo+rows) that peers pushed into this rank's landing
+// buffer (slot = row - lo) move to their place in the matrix.  Rows of this rank's own slice and rows nobody pushed
+// here (their mask lacks this rank's bit) are skipped.
+struct UnpackArgs {
+    const float *landing;
+    float *X;
+    const uint32_t *masks;
+    uint32_t lo, rows, my_lo, my_hi, D, self;
+};
+
+template <int VEC, bool EXACT>
+__global__ __launch_bounds__(256) void unpack_rows_kernel(const UnpackArgs u) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wpb = blockDim.x >> 6;
+    const uint32_t total = gridDim.x * wpb;
+    for (uint32_t r = blockIdx.x * wpb + (threadIdx.x >> 6); r < u.rows; r += total) {
+        const uint32_t row = u.lo + r;
+        if (row >= u.my_lo && row < u.my_hi) continue;
+        if (u.masks && !((u.masks[row] >> u.self) & 1u)) continue;
+        float t[VEC];
+        load_row<VEC, EXACT>(u.landing + (size_t)r * u.D, lane, u.D, t);
+        store_row<VEC, EXACT>(u.X + (size_t)row * u.D, lane, u.D, t);
+    }
 }
 
 // Flag barrier between minibatches, one 64-lane workgroup: lane r tells rank r "I have finished step `seq`" (a

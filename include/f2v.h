@@ -152,7 +152,11 @@ int f2v_synchronize(f2v_handle h);
  *                     the same f2v_srand / f2v_init_embeddings); on return every replica is complete
  *   f2v_push_detach   unmap the peers (also done by f2v_destroy)
  * "push_timeout_ms" (f2v_set_param, default 20000) bounds every wait of the flag barrier: a missing peer
- * makes the calls fail with F2V_ESTATE instead of hanging the GPU. */
+ * makes the calls fail with F2V_ESTATE instead of hanging the GPU.
+ * Matrices of 2 GiB and more cannot be mapped through HIP IPC (hipIpcOpenMemHandle does not return): such
+ * engines exchange through a mapped landing buffer of one minibatch (two halves of at most 512 MiB) that a
+ * small kernel unpacks behind the barrier -- automatically, or for any size with "push_landing" = 1 (set
+ * before f2v_push_export, on every rank alike).  A minibatch must then fit one half. */
 #define F2V_PUSH_MAX_RANKS 8
 #define F2V_PUSH_EXPORT_BYTES 256
 int f2v_push_export(f2v_handle h, void *handles_out);

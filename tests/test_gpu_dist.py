@@ -43,14 +43,16 @@ def _gloo_worker(rank, world, port, case, outdir, exchange="allgather"):
     eng = F.Engine(rp, ci, dim, device=0)
     eng.srand(1)
     eng.init_embeddings(0 if option in (5, 8, 11) else 1)
-    if exchange in ("push", "push_unfused"):
+    if exchange in ("push", "push_unfused", "push_landing", "push_landing_unfused"):
         # the engine's own exchange: peers' matrices mapped through HIP IPC (here: other processes on the same GPU),
         # rows pushed by a HIP kernel, device-side flag barrier; gloo only carries the handles
         comm = fdist.PushExchange(dist, rank, world)
         eng.set_param("push_timeout_ms", 8000)
-        if exchange == "push_unfused":  # rows pushed by a kernel of their own behind the step instead of by the step itself
+        if exchange.startswith("push_landing"):  # what matrices of 2 GiB and more use: rows travel through a landing buffer
+            eng.set_param("push_landing", 1)
+        if exchange.endswith("unfused"):  # rows pushed by a kernel of their own behind the step instead of by the step itself
             eng.set_param("push_fused", 0)
-            exchange = "push"
+        exchange = "push"
     elif exchange == "allgather":
         comm = fdist.HostStageComm(dist, rank, world)
     elif exchange == "need":
@@ -186,6 +188,21 @@ def test_push_exchange_with_a_separate_push_kernel(case, tmp_path):
     mp.spawn(_gloo_worker, args=(2, _free_port(), case, str(tmp_path), "push_unfused"), nprocs=2, join=True)
     want = _single_twice(case)
     for r in range(2):
+        assert np.array_equal(np.load(str(tmp_path / ("r%d.npy" % r))), want)
+
+
+@pytest.mark.parametrize("mode", ["push_landing", "push_landing_unfused"])
+@pytest.mark.parametrize("case", [("cora.mtx", 5, 3, 256, 128, 0), ("pubmed.mtx", 6, 2, 4096, 128, 0), ("karate.mtx", 7, 3, 16, 64, 0),
+                                  ("cora.mtx", 5, 2, 300, 100, 1)])
+def test_push_exchange_through_landing_buffers(case, mode, tmp_path):
+    """ "push_landing" = 1 (automatic for matrices of 2 GiB and more, which HIP IPC cannot map): the peers push a
+    minibatch's rows into a small mapped buffer, alternating halves, and unpack_rows_kernel moves them into the
+    matrix behind the barrier; the final completion pass goes minibatch by minibatch through the same buffer."""
+    import torch.multiprocessing as mp
+    world = 3 if case[0] == "cora.mtx" and mode == "push_landing" else 2
+    mp.spawn(_gloo_worker, args=(world, _free_port(), case, str(tmp_path), mode), nprocs=world, join=True)
+    want = _single_twice(case)
+    for r in range(world):
         assert np.array_equal(np.load(str(tmp_path / ("r%d.npy" % r))), want)
 
 
