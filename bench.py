@@ -21,6 +21,7 @@ reference binary oracle/_ref timed on this box's host cores on a bounded sample)
 import argparse
 import json
 import os
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -154,6 +155,7 @@ def main():
                     help="before the W warmup steps: epochs of the same workload until this much time has passed -- after any idle "
                          "gap the GPU's power controller needs ~15 ms of steady load before epoch times stop moving "
                          "(profiles/r01_idle_effect.txt); 0 = none")
+    ap.add_argument("--no-preflight", action="store_true", help="N>1: skip the child process that rehearses IPC mapping and remote stores first")
     ap.add_argument("--no-verify", action="store_true", help="N>1: skip the bit-for-bit check of every replica against a single-GPU run")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: self-test of the N>1 plumbing on a one-GPU box (all ranks on device 0, exchange through the host)")
@@ -177,6 +179,22 @@ def main():
     torch = None
     host_group = None
     use_dist = world > 1 or args.force_dist
+    preflight_ok = True
+    if world > 1 and args.exchange == "push" and not args.no_preflight:
+        # Before this process touches the GPU: a throw-away child rehearses the IPC mapping and the remote stores the push
+        # exchange needs (the ranks' children meet through files).  If it fails, faults or never returns, the run uses RCCL.
+        meet = "/tmp/f2v_preflight_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"))
+        mbytes = ((1 << args.scale) + 4096) * args.dim * 4
+        if mbytes >= 0x7FF00000:
+            mbytes = 2 * min(512 << 20, mbytes // 2)  # such engines map a landing buffer instead of the matrices
+        pre_dev = 0 if args.dist_backend == "gloo" else local_rank
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ipc_preflight.py"), str(pre_dev), str(rank), str(world), meet,
+                                str(mbytes), "60"], timeout=120, stdout=subprocess.DEVNULL)
+            preflight_ok = r.returncode == 0
+        except subprocess.TimeoutExpired:
+            preflight_ok = False
+        note(rank, "IPC preflight (%d MiB buffers between %d processes): %s" % (mbytes >> 20, world, "passed" if preflight_ok else "FAILED"))
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -199,6 +217,16 @@ def main():
                 log("bench[rank %d]: no gloo group (%r); using the RCCL group for the handle exchange" % (rank, exn))
                 host_group = None
 
+    if use_dist and world > 1 and args.exchange == "push" and not args.no_preflight:
+        oks = [None] * world
+        dist.all_gather_object(oks, bool(preflight_ok), group=host_group)
+        if rank == 0:  # every rank's child has ended
+            shutil.rmtree(meet, ignore_errors=True)
+        if not all(oks):
+            state_note = "IPC preflight failed on rank(s) %s: RCCL all-gather instead of the push exchange" % ([i for i, o in enumerate(oks) if not o],)
+            log("bench[rank %d]: %s" % (rank, state_note))
+            args.exchange = "allgather"
+            args.preflight_note = state_note
     if use_dist and world > 1:
         # one rank generates (or finds) the cached graph, the others read the cache
         if rank == 0:
@@ -226,7 +254,7 @@ def main():
             if args.dist_backend == "nccl":
                 torch.cuda.synchronize()
 
-    state = {"exchange": args.exchange, "comm": None, "note": None}
+    state = {"exchange": args.exchange, "comm": None, "note": getattr(args, "preflight_note", None)}
 
     def make_comm():
         """The exchange this run uses; the push exchange is attached (and self-tested) here, once."""
@@ -324,11 +352,19 @@ def main():
     def verify(schedule):
         """Every rank: the same epochs on ONE engine (no sharding, no exchange) must give this replica bit for bit."""
         ref = F.Engine(rowptr, colids, args.dim, device=local_rank)
+        for kv in args.param:
+            pk, pv = kv.split("=")
+            if not pk.startswith("push_"):
+                ref.set_param(pk, int(pv))
         ref.set_param("hub_chunk", eng.get_param("hub_chunk"))  # the chunk is part of the summation order
         ref.srand(1)
         ref.init_embeddings(F._lib.INIT_SYMMETRIC if args.option in (5, 8, 11) else F._lib.INIT_UNIT)
-        for k, b in schedule:
-            ref.train(args.option, k, b, 5, 0.02, 0)
+        for i, (k, b) in enumerate(schedule):
+            try:
+                ref.train(args.option, k, b, 5, 0.02, 0)
+            except Exception:
+                note(rank, "single-GPU replay failed in call %d of %d (%d epochs at batch %d)" % (i, len(schedule), k, b))
+                raise
         same = bool(np.array_equal(ref.get_embeddings(), eng.get_embeddings()))
         ref.close()
         t = torch.tensor([1 if same else 0], dtype=torch.int32, device="cuda" if args.dist_backend == "nccl" else "cpu")

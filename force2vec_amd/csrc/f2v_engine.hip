@@ -17,6 +17,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <type_traits>
 #include <vector>
@@ -150,24 +151,45 @@ void drop_plans(f2v_ctx *c) {
     c->d_items_valid = c->d_hubs_valid = 0;
 }
 
+// items one workgroup of the step kernel covers, and tree nodes one workgroup covers (= its wavefronts)
+uint32_t items_per_block(const f2v_ctx *c) {
+    const bool quarter = c->use_quarter && (c->D == 16 || c->D == 32 || c->D == 64 || c->D == 128 || c->D == 256);
+    const uint32_t per_wave = !quarter ? 1u : (c->D == 16 ? 16u : c->D == 32 ? 8u : 4u);
+    return per_wave * (uint32_t)c->waves_per_block;
+}
+
 // Work items of one launch (rows [row_lo,row_hi), CSR neighbours or walk samples): a whole row, or
-// `chunk`-neighbour pieces of a hub row, sorted longest first (the longest waves start first and
-// the four quarters of a wave get items of nearly equal length).  Host-side, cached per launch shape.
+// `chunk`-neighbour pieces of a hub row, longest first (the longest waves start first and the four quarters of a
+// wave get items of nearly equal length).  Host-side, cached per launch shape.
+//
+// Who may wait for whom.  Tree nodes WAIT for the partial sums they add (one launch per minibatch), so what they wait
+// for must be running or done whatever else the GPU is doing.  Workgroups go to the 8 XCDs round robin (workgroup b
+// to XCD b mod 8) and every XCD starts its workgroups in index order; inside one process that is enough.  But a
+// second process whose own waiting nodes fill one XCD can keep this launch's first workgroups from starting there
+// while the other seven XCDs run ahead into the tree nodes -- two such processes can wait for each other (seen with
+// three replays sharing one card: bounded by the time-out, but seconds long).  So the bulk of the waiting -- the
+// lowest tree level, one node per group of `fanin` pieces -- is tied to an XCD: a group gets a CLASS 0..7 and its
+// pieces and its node are placed in workgroups whose index is congruent to the class modulo 8 (whole rows and, at
+// the very end, inert padding items fill the gaps): such a node only ever waits for workgroups of its OWN XCD with
+// a smaller index, which that XCD has started before it.  The upper levels are 1/fanin as many nodes -- too few to
+// fill an XCD, so they cannot take part in such a ring -- and stay unconstrained.
 const Plan &plan_for(f2v_ctx *c, uint32_t row_lo, uint32_t row_hi, bool walk) {
     const auto key = std::make_tuple(row_lo, row_hi, walk ? 1 : 0);
     auto itp = c->plans.find(key);
     if (itp != c->plans.end()) return itp->second;
     if (c->h_items.size() > 8 * ((size_t)c->n + 1024)) drop_plans(c);  // bound the cache
+    constexpr uint32_t kXcds = 8;
+    const uint32_t ipb = items_per_block(c), npb = (uint32_t)c->waves_per_block;
     Plan p;
     p.item_off = c->h_items.size();
-    std::vector<Item> items;
-    items.reserve(row_hi - row_lo);
-    struct Node { uint32_t row, in_slot, n; };
+    std::vector<Item> whole;  // rows that stay one item
+    whole.reserve(row_hi - row_lo);
+    struct Node { uint32_t row, in_slot, n, cls; };
     std::vector<Node> cur, nxt;
     uint32_t slots = 0;
     for (uint32_t i = row_lo; i < row_hi; i++) {
         if (walk) {
-            items.push_back(Item{i, i * (uint32_t)kWalkLength, (uint32_t)kWalkLength, kItemFirst | kItemLast});
+            whole.push_back(Item{i, i * (uint32_t)kWalkLength, (uint32_t)kWalkLength, kItemFirst | kItemLast});
             p.nnz += kWalkLength;
             continue;
         }
@@ -175,22 +197,78 @@ const Plan &plan_for(f2v_ctx *c, uint32_t row_lo, uint32_t row_hi, bool walk) {
         p.nnz += deg;
         if (c->chunk != 0 && deg > c->chunk) {
             const uint32_t nc = (deg + c->chunk - 1) / c->chunk;
-            cur.push_back(Node{i, slots, nc});
-            for (uint32_t k = 0; k < nc; k++) {
-                const uint32_t b = k * c->chunk, e = std::min(deg, b + c->chunk);
-                items.push_back(Item{i, rp + b, e - b, kItemPartial | (k == 0 ? kItemFirst : 0u) | (k == nc - 1 ? kItemLast : 0u) | (slots + k)});
-            }
+            cur.push_back(Node{i, slots, nc, 0});
             slots += nc;
         } else {
-            items.push_back(Item{i, rp, deg, kItemFirst | kItemLast});
+            whole.push_back(Item{i, rp, deg, kItemFirst | kItemLast});
         }
     }
-    std::stable_sort(items.begin(), items.end(), [](const Item &x, const Item &y) { return x.cnt > y.cnt; });
-    c->h_items.insert(c->h_items.end(), items.begin(), items.end());
-    p.n_items = (uint32_t)items.size();
     p.n_hubs = (uint32_t)cur.size();
     p.n_chunks = slots;
-    // combine trees, level by level: groups of `fanin` partials are added in order until one is left
+    std::vector<Item> items;
+    items.reserve(whole.size() + slots + 64);
+    const Item pad_item{0, 0, 0, kItemPad};
+    const FinItem pad_node{0, 0, kFinToStage, 0};
+    std::stable_sort(whole.begin(), whole.end(), [](const Item &x, const Item &y) { return x.cnt > y.cnt; });
+    if (!cur.empty()) {
+        // Lowest tree level first: one node per GROUP of `fanin` consecutive pieces of a hub.  A group -- its pieces and
+        // its node -- gets a class, groups take the classes in turn (a giant hub thus spreads over all XCDs).
+        std::vector<Item> queue[kXcds];
+        std::vector<FinItem> nq[kXcds];
+        uint32_t next_cls = 0;
+        for (const Node &nd : cur) {
+            const uint32_t rp = c->rowptr[nd.row], deg = c->rowptr[nd.row + 1] - rp;
+            const uint32_t G = c->fanin < 2 ? nd.n : c->fanin;
+            const uint32_t nout = (nd.n + G - 1) / G;
+            for (uint32_t o = 0; o < nout; o++) {
+                const uint32_t cls = next_cls++ % kXcds, k0 = o * G, k1 = std::min(nd.n, k0 + G);
+                for (uint32_t k = k0; k < k1; k++) {
+                    const uint32_t b = k * c->chunk, e = std::min(deg, b + c->chunk);
+                    queue[cls].push_back(Item{nd.row, rp + b, e - b, kItemPartial | (k == 0 ? kItemFirst : 0u) | (k == nd.n - 1 ? kItemLast : 0u) | (nd.in_slot + k)});
+                }
+                nq[cls].push_back(FinItem{nd.in_slot + k0, k1 - k0, nout == 1 ? kFinToStage : slots + o, nd.row});
+            }
+            if (nout > 1) {
+                nxt.push_back(Node{nd.row, slots, nout, 0});
+                slots += nout;
+            }
+        }
+        for (auto &q : queue) std::stable_sort(q.begin(), q.end(), [](const Item &x, const Item &y) { return x.cnt > y.cnt; });
+        // one workgroup per class per round; a class that has run out of pieces hands its workgroups to whole rows
+        size_t pos[kXcds] = {}, wpos = 0;
+        for (bool more = true; more;) {
+            more = false;
+            for (uint32_t k = 0; k < kXcds; k++) {
+                for (uint32_t j = 0; j < ipb; j++) {
+                    if (pos[k] < queue[k].size()) items.push_back(queue[k][pos[k]++]);
+                    else if (wpos < whole.size()) items.push_back(whole[wpos++]);
+                    else items.push_back(pad_item);
+                }
+                more = more || pos[k] < queue[k].size();
+            }
+        }
+        items.insert(items.end(), whole.begin() + wpos, whole.end());
+        // the nodes' workgroups follow the items': their first one must again be a multiple of 8
+        while (items.size() % ((size_t)kXcds * ipb) != 0) items.push_back(pad_item);
+        p.fin_off[0] = c->h_hubs.size();
+        size_t npos[kXcds] = {};
+        for (bool more = true; more;) {
+            more = false;
+            for (uint32_t k = 0; k < kXcds; k++) {
+                for (uint32_t j = 0; j < npb; j++) c->h_hubs.push_back(npos[k] < nq[k].size() ? nq[k][npos[k]++] : pad_node);
+                more = more || npos[k] < nq[k].size();
+            }
+        }
+        p.fin_cnt[0] = (uint32_t)(c->h_hubs.size() - p.fin_off[0]);
+        p.n_levels = 1;
+        cur.swap(nxt);
+    } else {
+        items.insert(items.end(), whole.begin(), whole.end());
+    }
+    c->h_items.insert(c->h_items.end(), items.begin(), items.end());
+    p.n_items = (uint32_t)items.size();
+    // upper levels: groups of `fanin` sums are added in order until one is left.  Their nodes are few (1/fanin of the
+    // level below): wherever they wait, they cannot fill an XCD, so they are packed without regard to classes.
     while (!cur.empty() && p.n_levels < kMaxFinLevels) {
         p.fin_off[p.n_levels] = c->h_hubs.size();
         nxt.clear();
@@ -202,7 +280,7 @@ const Plan &plan_for(f2v_ctx *c, uint32_t row_lo, uint32_t row_hi, bool walk) {
             } else {
                 for (uint32_t o = 0; o < nout; o++)
                     c->h_hubs.push_back(FinItem{nd.in_slot + o * G, std::min(G, nd.n - o * G), slots + o, nd.row});
-                nxt.push_back(Node{nd.row, slots, nout});
+                nxt.push_back(Node{nd.row, slots, nout, 0});
                 slots += nout;
             }
         }
@@ -243,7 +321,10 @@ int upload_plans(f2v_ctx *c) {
         if (c->d_ready) (void)hipFree(c->d_ready);
         c->d_ready = nullptr;
         HIPC(hipMalloc((void **)&c->d_ready, need_slots * sizeof(uint32_t)));
-        HIPC(hipMemset(c->d_ready, 0, need_slots * sizeof(uint32_t)));
+        // hipMemset on device memory may return before the fill has run (it is ordered on the NULL stream, which this
+        // engine's non-blocking stream does not wait for): a late fill would wipe the first launch's flags
+        HIPC(hipMemsetAsync(c->d_ready, 0, need_slots * sizeof(uint32_t), c->stream));
+        HIPC(hipStreamSynchronize(c->stream));
         c->partial_slots = need_slots;
     }
     if (c->h_items.size() > c->d_items_valid)
@@ -314,9 +395,14 @@ int flush_pending(f2v_ctx *c) {
 
 // after a stream synchronisation: did a kernel give up a bounded wait?
 int check_kernel_err(f2v_ctx *c, const char *where) {
-    uint32_t e = 0;
-    HIPC(hipMemcpy(&e, c->d_kerr, sizeof e, hipMemcpyDeviceToHost));
-    if (e) return fail(F2V_ESTATE, "%s: a combine-tree node waited for its inputs in vain (code %u); set \"merge_finalize\" = 0", where, e);
+    uint32_t e[8] = {};
+    HIPC(hipMemcpy(e, c->d_kerr, sizeof e, hipMemcpyDeviceToHost));
+    if (e[0]) {
+        (void)hipMemset(c->d_kerr, 0, sizeof e);
+        (void)hipDeviceSynchronize();
+        return fail(F2V_ESTATE, "%s: %u combine-tree waits gave up (first: node %u of %u [first dependent %u] on slot %u, flag %u, launch %u); set \"merge_finalize\" = 0",
+                    where, e[1], e[2], e[6], e[7], e[3], e[4], e[5]);
+    }
     return F2V_OK;
 }
 
@@ -331,6 +417,16 @@ int math_of_option(int option) {
 
 // Launch one minibatch step (+ hub finalisation) on the handle's stream.  d_ids: device sample ids.
 void fill_targets(const f2v_ctx *c, PushTargets &t, int which, uint32_t batch_lo, const uint32_t *d_masks);
+
+// bound of a combine-tree node's wait: 5 s of the 100 MHz wall clock (F2V_TREE_TIMEOUT_MS overrides, for experiments)
+unsigned long long tree_timeout_ticks() {
+    static const unsigned long long ticks = [] {
+        const char *e = getenv("F2V_TREE_TIMEOUT_MS");
+        const long ms = e ? atol(e) : 5000;
+        return (unsigned long long)(ms > 0 ? ms : 5000) * 100000ull;
+    }();
+    return ticks;
+}
 
 // push_masks / push: a sharded run's step -- the kernels also store every finished row into the second matrix of
 // the peers that read it (push_masks == nullptr: of every peer).
@@ -379,7 +475,7 @@ int launch_step(f2v_ctx *c, int math, uint32_t batch_lo, uint32_t batch_hi, uint
         for (int lev = 0; lev < plan.n_levels; lev++) a.fin_n += plan.fin_cnt[lev];  // the levels are stored back to back
         a.ready = c->d_ready;
         a.err = c->d_kerr;
-        a.timeout_ticks = 500000000ull;  // 5 s of the 100 MHz wall clock
+        a.timeout_ticks = tree_timeout_ticks();
         a.seq = ++c->launch_seq;
         if (a.seq == 0) a.seq = ++c->launch_seq;  // 0 is what fresh flags hold
         blocks += (a.fin_n + wpb - 1) / wpb;
@@ -432,18 +528,18 @@ int launch_step(f2v_ctx *c, int math, uint32_t batch_lo, uint32_t batch_hi, uint
         t.f.push = a.push;
         t.ready = c->d_ready;
         t.err = c->d_kerr;
-        t.timeout_ticks = 500000000ull;  // 5 s of the 100 MHz wall clock
+        t.timeout_ticks = tree_timeout_ticks();
         t.seq = ++c->launch_seq;
         if (t.seq == 0) t.seq = ++c->launch_seq;  // 0 is what fresh flags hold
         t.first_dep = plan.fin_cnt[0];
-        const uint32_t fb = (t.f.n_items + 3) / 4;
+        const uint32_t fb = (t.f.n_items + wpb - 1) / wpb;  // the node layout counts on `wpb` nodes per workgroup
         rc = dispatch_layout(c, [&](auto V, auto E) {
             constexpr int VEC = decltype(V)::value;
             constexpr bool EX = decltype(E)::value;
             if (math == 5)
-                hipLaunchKernelGGL((hub_finalize_tree_kernel<5, VEC, EX>), dim3(fb), dim3(256), 0, c->stream, t);
+                hipLaunchKernelGGL((hub_finalize_tree_kernel<5, VEC, EX>), dim3(fb), dim3(64 * wpb), 0, c->stream, t);
             else
-                hipLaunchKernelGGL((hub_finalize_tree_kernel<6, VEC, EX>), dim3(fb), dim3(256), 0, c->stream, t);
+                hipLaunchKernelGGL((hub_finalize_tree_kernel<6, VEC, EX>), dim3(fb), dim3(64 * wpb), 0, c->stream, t);
         });
         if (rc != F2V_OK) return rc;
         HIPC(hipGetLastError());
@@ -720,7 +816,8 @@ int f2v_create(const uint32_t *rowptr, const uint32_t *colids, uint32_t n, uint6
     for (int k = 0; k < 2; k++) HIPB(hipMalloc((void **)&c->d_X[k], ((size_t)n + kPadRows) * dim * sizeof(float)));
     HIPB(hipMalloc((void **)&c->d_table, kSmTableSize * sizeof(float)));
     HIPB(hipMalloc((void **)&c->d_kerr, 64));
-    HIPB(hipMemset(c->d_kerr, 0, 64));
+    HIPB(hipMemsetAsync(c->d_kerr, 0, 64, c->stream));
+    HIPB(hipStreamSynchronize(c->stream));
     HIPB(hipMemcpy(c->d_rowptr, rowptr, ((size_t)n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
     if (nnz) HIPB(hipMemcpy(c->d_colids, colids, nnz * sizeof(uint32_t), hipMemcpyHostToDevice));
     float table[kSmTableSize];
@@ -853,7 +950,14 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
         return F2V_OK;
     }
     if (!strcmp(name, "quarter_wave")) {
-        c->use_quarter = value != 0;
+        if (c->use_quarter != (value != 0)) {  // the item layout follows the kernel's items per workgroup
+            HIPC(hipSetDevice(c->device));
+            int rc = flush_pending(c);
+            if (rc != F2V_OK) return rc;
+            HIPC(hipStreamSynchronize(c->stream));
+            c->use_quarter = value != 0;
+            drop_plans(c);
+        }
         return F2V_OK;
     }
     if (!strcmp(name, "fast_rng")) {
@@ -888,7 +992,14 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
     }
     if (!strcmp(name, "waves_per_block")) {
         if (value != 1 && value != 2 && value != 4) return fail(F2V_EINVAL, "waves_per_block must be 1, 2 or 4");
-        c->waves_per_block = (int)value;
+        if (c->waves_per_block != (int)value) {
+            HIPC(hipSetDevice(c->device));
+            int rc = flush_pending(c);
+            if (rc != F2V_OK) return rc;
+            HIPC(hipStreamSynchronize(c->stream));
+            c->waves_per_block = (int)value;
+            drop_plans(c);
+        }
         return F2V_OK;
     }
     return fail(F2V_EINVAL, "f2v_set_param: unknown parameter '%s'", name);
@@ -1496,6 +1607,89 @@ int f2v_test_gather_calibration(int device, uint32_t rows, uint32_t reps) {
     HIPC(hipGetLastError());
     HIPC(hipDeviceSynchronize());
     (void)hipFree(d_t); (void)hipFree(d_i); (void)hipFree(d_o);
+    return F2V_OK;
+}
+
+// Stand-alone rehearsal of what f2v_push_attach + the push kernels need from the machine, meant to run in a
+// THROW-AWAY process before the real engines exist: allocate `bytes` of device memory and a fine-grained flag array
+// on `device`, swap IPC handles with the other ranks through files in `dir`, map theirs, store a word at both ends of
+// every peer's buffer and into every peer's flags from a kernel, and check what the peers stored here.  Whatever goes
+// wrong -- a mapping call that never returns, a fault on the first remote store -- happens to this process.
+int f2v_test_ipc_preflight(int device, uint32_t rank, uint32_t world, const char *dir, uint64_t bytes, double timeout_s) {
+    if (!dir || world == 0 || world > (uint32_t)kMaxRanks || rank >= world || bytes < 4096) return fail(F2V_EINVAL, "f2v_test_ipc_preflight: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(F2V_ENODEV, "f2v_test_ipc_preflight: device %d of %d", device, ndev);
+    HIPC(hipSetDevice(device));
+    uint32_t *data = nullptr;
+    unsigned long long *flags = nullptr;
+    HIPC(hipMalloc((void **)&data, bytes));
+    HIPC(hipMemset(data, 0, 4096));
+    HIPC(hipMemset((char *)data + bytes - 4096, 0, 4096));
+    HIPC(hipExtMallocWithFlags((void **)&flags, 4096, hipDeviceMallocFinegrained));
+    HIPC(hipMemset(flags, 0, 4096));
+    HIPC(hipDeviceSynchronize());
+    struct Blob { hipIpcMemHandle_t data, flags; } mine, theirs;
+    HIPC(hipIpcGetMemHandle(&mine.data, data));
+    HIPC(hipIpcGetMemHandle(&mine.flags, flags));
+    const auto t0 = std::chrono::steady_clock::now();
+    auto late = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s; };
+    auto path = [&](const char *what, uint32_t r) { return std::string(dir) + "/" + what + "." + std::to_string(r); };
+    auto publish = [&](const char *what, const void *p, size_t len) -> bool {
+        const std::string tmp = path(what, rank) + ".tmp";
+        FILE *f = fopen(tmp.c_str(), "wb");
+        if (!f) return false;
+        const bool ok = fwrite(p, 1, len, f) == len;
+        return (fclose(f) == 0) && ok && rename(tmp.c_str(), path(what, rank).c_str()) == 0;
+    };
+    auto await = [&](const char *what, uint32_t r, void *p, size_t len) -> bool {
+        for (;;) {
+            FILE *f = fopen(path(what, r).c_str(), "rb");
+            if (f) {
+                const size_t got = fread(p, 1, len, f);
+                fclose(f);
+                if (got == len) return true;
+            }
+            if (late()) return false;
+            std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        }
+    };
+    if (!publish("handles", &mine, sizeof mine)) return fail(F2V_EIO, "f2v_test_ipc_preflight: cannot write into %s", dir);
+    PreflightArgs a{};
+    a.self = rank;
+    a.world = world;
+    a.value = 0xF2F00000u + rank;
+    a.last_word = bytes / 4 - 1;
+    for (uint32_t r = 0; r < world; r++) {
+        if (r == rank) { a.data[r] = data; a.flags[r] = flags; continue; }
+        if (!await("handles", r, &theirs, sizeof theirs)) return fail(F2V_ESTATE, "f2v_test_ipc_preflight: rank %u never published its handles", r);
+        HIPC(hipIpcOpenMemHandle((void **)&a.data[r], theirs.data, hipIpcMemLazyEnablePeerAccess));
+        HIPC(hipIpcOpenMemHandle((void **)&a.flags[r], theirs.flags, hipIpcMemLazyEnablePeerAccess));
+    }
+    hipLaunchKernelGGL(preflight_write_kernel, dim3(1), dim3(64), 0, 0, a);
+    HIPC(hipGetLastError());
+    HIPC(hipDeviceSynchronize());
+    char one = 1;
+    if (!publish("stored", &one, 1)) return fail(F2V_EIO, "f2v_test_ipc_preflight: cannot write into %s", dir);
+    for (uint32_t r = 0; r < world; r++)
+        if (r != rank && !await("stored", r, &one, 1)) return fail(F2V_ESTATE, "f2v_test_ipc_preflight: rank %u never finished its stores", r);
+    std::vector<uint32_t> head(world), tail(world);
+    std::vector<unsigned long long> fl(world);
+    HIPC(hipMemcpy(head.data(), data, world * 4, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(tail.data(), data + a.last_word + 1 - world, world * 4, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(fl.data(), flags, world * 8, hipMemcpyDeviceToHost));
+    int bad = 0;
+    for (uint32_t r = 0; r < world; r++) {
+        const uint32_t want = 0xF2F00000u + r;
+        if (head[r] != want || tail[world - 1 - r] != want || fl[r] != want) bad++;
+    }
+    if (!publish("checked", &one, 1)) return fail(F2V_EIO, "f2v_test_ipc_preflight: cannot write into %s", dir);
+    for (uint32_t r = 0; r < world; r++)  // nobody unmaps or frees while a peer may still be reading
+        if (r != rank && !await("checked", r, &one, 1)) break;
+    for (uint32_t r = 0; r < world; r++)
+        if (r != rank) { (void)hipIpcCloseMemHandle(a.data[r]); (void)hipIpcCloseMemHandle(a.flags[r]); }
+    (void)hipFree(data);
+    (void)hipFree(flags);
+    if (bad) return fail(F2V_ENODEV, "f2v_test_ipc_preflight: %d of %u peers' stores did not arrive intact", bad, world);
     return F2V_OK;
 }
 

@@ -55,6 +55,7 @@ struct Item {
 constexpr uint32_t kItemPartial = 1u << 31;  // store the force sum to partials[slot] (hub chunk), not the new row
 constexpr uint32_t kItemFirst = 1u << 30;    // first chunk of its row (sigmoid: accumulates onto x_i)
 constexpr uint32_t kItemLast = 1u << 29;     // last chunk of its row: also takes the negative samples
+constexpr uint32_t kItemPad = 1u << 28;      // inert: fills a workgroup so that the next hub piece lands on the right XCD
 constexpr uint32_t kItemSlotMask = (1u << 28) - 1;
 
 // One node of a hub row's combine tree: add partial rows [in_slot, in_slot+n) in order.
@@ -364,6 +365,7 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
     if (w >= a.n_items) return;
 
     const Item it = a.items[w];
+    if (it.flags & kItemPad) return;
     const uint32_t row = it.row;
     const bool partial = (it.flags & kItemPartial) != 0;
     const bool first_chunk = (it.flags & kItemFirst) != 0;
@@ -502,16 +504,22 @@ __device__ __forceinline__ void finalize_tree_node(const FinalizeTreeArgs &a, ui
     const FinalizeArgs &f = a.f;
     if (w >= f.n_items) return;
     const FinItem h = f.items[w];
+    if (h.n == 0u) return;  // padding
     const uint32_t D = f.D;
     const float *p = f.partials + (size_t)h.in_slot * D;
     float Y[VEC];
     if (w >= a.first_dep) {
         const unsigned long long t0 = wall_clock64();
         for (uint32_t c = lane; c < h.n; c += 64u) {
-            while (__hip_atomic_load(a.ready + h.in_slot + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.seq) {
+            uint32_t seen;
+            while ((seen = __hip_atomic_load(a.ready + h.in_slot + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != a.seq) {
                 __builtin_amdgcn_s_sleep(1);
                 if (wall_clock64() - t0 > a.timeout_ticks) {
+                    // err[0] code, [1] how many waits gave up, [2..6] the first of them: node, slot, flag seen, seq, node count
                     __hip_atomic_store(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__hip_atomic_fetch_add(a.err + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                        a.err[2] = w; a.err[3] = h.in_slot + c; a.err[4] = seen; a.err[5] = a.seq; a.err[6] = f.n_items; a.err[7] = a.first_dep;
+                    }
                     break;
                 }
             }
@@ -724,10 +732,11 @@ __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
 
     // this item's lanes (lane groups past the end of the list idle with cnt = 0)
     const uint32_t idx = IPW * w + q;
-    const bool active = idx < a.n_items;
+    bool active = idx < a.n_items;
     Item it;
     if (active) it = a.items[idx];
     else { it.row = 0; it.nb = 0; it.cnt = 0; it.flags = 0; }
+    if (it.flags & kItemPad) { active = false; it.flags = 0; }
     const uint32_t row = it.row;
     const bool partial = (it.flags & kItemPartial) != 0;
     const bool first_chunk = (it.flags & kItemFirst) != 0;
@@ -818,6 +827,7 @@ __global__ __launch_bounds__(256) void hub_finalize_kernel(const FinalizeArgs f)
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     if (w >= f.n_items) return;
     const FinItem h = f.items[w];
+    if (h.n == 0u) return;  // padding (the node layout of the one-launch variants)
     const uint32_t D = f.D;
     const float *p = f.partials + (size_t)h.in_slot * D;
     float Y[VEC];
@@ -1035,6 +1045,27 @@ __global__ __launch_bounds__(256) void gather_calibration_kernel(const float *ta
     }
     const float s = (acc.x + acc.y) + (acc.z + acc.w);
     if (s == 12345.678f) out[0] = s;  // practically never: keeps the loads from being optimised away
+}
+
+// IPC preflight (f2v_test_ipc_preflight): thread q stores a word into the mapped buffer and the mapped flag array of rank q
+struct PreflightArgs {
+    uint32_t *data[kMaxRanks];
+    unsigned long long *flags[kMaxRanks];
+    uint32_t self, world, value;
+    uint64_t last_word;  // index of the last 32-bit word of the data buffers (the far end of the mapping is exercised too)
+};
+
+__global__ void preflight_write_kernel(const PreflightArgs a) {
+    const uint32_t q = threadIdx.x;
+    if (q >= a.world) return;
+    uint32_t *d = a.data[0];
+    unsigned long long *f = a.flags[0];
+#pragma unroll
+    for (int k = 1; k < kMaxRanks; ++k)
+        if ((uint32_t)k == q) { d = a.data[k]; f = a.flags[k]; }
+    __hip_atomic_store(d + a.self, a.value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(d + a.last_word - a.self, a.value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(f + a.self, (unsigned long long)a.value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Self-test of the reduction order: out[r] = tree sum of in[r*width .. +width)

@@ -235,6 +235,10 @@ int f2v_test_wave_reduce(int device, const float *in, uint32_t rows, uint32_t wi
 /* The push exchange between engines of ONE process on one device (direct pointers instead of HIP IPC; every
  * engine is driven by its own host thread): runs the push kernels, masks and flag barriers under a profiler. */
 int f2v_test_push_attach_local(f2v_handle h, uint32_t rank, uint32_t world, const f2v_handle *all);
+/* Rehearsal of the push exchange's needs (IPC mapping of `bytes` of device memory and of fine-grained flags between
+ * `world` processes that meet through files in `dir`, remote stores from a kernel), for a throw-away process to run
+ * before the real engines exist: a mapping call that never returns or a faulting remote store then costs only it. */
+int f2v_test_ipc_preflight(int device, uint32_t rank, uint32_t world, const char *dir, uint64_t bytes, double timeout_s);
 /* PMC calibration: `reps` launches that each gather `rows` distinct 512-byte rows exactly once with
  * the step kernel's access pattern (known HBM read volume rows*516 bytes per launch). */
 int f2v_test_gather_calibration(int device, uint32_t rows, uint32_t reps);
