@@ -183,14 +183,16 @@ def main():
     if world > 1 and args.exchange == "push" and not args.no_preflight:
         # Before this process touches the GPU: a throw-away child rehearses the IPC mapping and the remote stores the push
         # exchange needs (the ranks' children meet through files).  If it fails, faults or never returns, the run uses RCCL.
-        meet = "/tmp/f2v_preflight_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"))
         mbytes = ((1 << args.scale) + 4096) * args.dim * 4
         if mbytes >= 0x7FF00000:
             mbytes = 2 * min(512 << 20, mbytes // 2)  # such engines map a landing buffer instead of the matrices
         pre_dev = 0 if args.dist_backend == "gloo" else local_rank
+        # where the ranks' children meet: all ranks are children of one launcher (torch.distributed.run), whose pid makes
+        # the name unique to this launch; with another launcher the children time out and the run falls back
+        meet = "/tmp/f2v_preflight_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
         try:
             r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ipc_preflight.py"), str(pre_dev), str(rank), str(world), meet,
-                                str(mbytes), "60"], timeout=120, stdout=subprocess.DEVNULL)
+                                str(mbytes), "60"], timeout=150, stdout=subprocess.DEVNULL)
             preflight_ok = r.returncode == 0
         except subprocess.TimeoutExpired:
             preflight_ok = False
