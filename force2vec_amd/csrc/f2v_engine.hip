@@ -1313,6 +1313,9 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
     HIPC(hipEventCreate(&ev1));
     HIPC(hipEventRecord(ev0, c->stream));
     std::vector<uint32_t> walks;
+    // F2V_PUSH_CHAOS=<seed>: protocol test -- every rank stalls at random minibatches (different ones on every rank)
+    unsigned long long chaos = 0;
+    if (const char *e = getenv("F2V_PUSH_CHAOS")) chaos = (strtoull(e, nullptr, 10) + 1) * 0x9E3779B97F4A7C15ull + c->push.rank * 0xD1B54A32D192ED03ull;
     const bool graphed = c->use_graph && math != 7 && all_upfront && iters >= 2 && !sharded;
     if (graphed) {
         // hipGraph replay: an epoch's launch chain is identical every epoch except for (a) which of the two matrices
@@ -1372,6 +1375,13 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
             const uint32_t hi = (uint32_t)std::min<uint64_t>((uint64_t)lo + batch, n);
             uint32_t my_lo = lo, my_hi = hi;
             if (sharded) shard_of(c, math == 7, lo, hi, c->push.rank, c->push.world, &my_lo, &my_hi);
+            if (exchanging && chaos) {  // test hook: random host-side stalls skew the ranks against each other
+                chaos = chaos * 6364136223846793005ull + 1442695040888963407ull;
+                if (((chaos >> 33) & 7u) == 0u) {
+                    HIPC(hipStreamSynchronize(c->stream));
+                    std::this_thread::sleep_for(std::chrono::microseconds((chaos >> 40) % 3000u));
+                }
+            }
             if ((rc = launch_step(c, math, lo, hi, my_lo, my_hi, d_epoch_ids + (size_t)b * stride, ns, lr, bs_mode, exchanging && c->push.fused, d_masks)) != F2V_OK) return rc;
             if (exchanging) {
                 if (!c->push.fused && (rc = launch_push(c, c->cur ^ 1, d_masks, lo, my_lo, my_hi)) != F2V_OK) return rc;

@@ -206,6 +206,21 @@ def test_push_exchange_through_landing_buffers(case, mode, tmp_path):
         assert np.array_equal(np.load(str(tmp_path / ("r%d.npy" % r))), want)
 
 
+@pytest.mark.parametrize("mode", ["push", "push_unfused", "push_landing", "push_landing_unfused"])
+def test_push_exchange_with_skewed_ranks(mode, tmp_path, monkeypatch):
+    """F2V_PUSH_CHAOS: every rank drains its stream and sleeps up to 3 ms at random minibatches (other ones on every
+    rank), so ranks run ahead of and behind each other by whole minibatches: the barrier, the two landing-buffer halves
+    and the epoch's matrix swap must keep every replica bit-identical all the same."""
+    import torch.multiprocessing as mp
+    monkeypatch.setenv("F2V_PUSH_CHAOS", "7")
+    case = ("pubmed.mtx", 5, 4, 1024, 64, 0)
+    mp.spawn(_gloo_worker, args=(3, _free_port(), case, str(tmp_path), mode), nprocs=3, join=True)
+    monkeypatch.delenv("F2V_PUSH_CHAOS")
+    want = _single_twice(case)
+    for r in range(3):
+        assert np.array_equal(np.load(str(tmp_path / ("r%d.npy" % r))), want)
+
+
 def test_push_barrier_times_out_instead_of_hanging(tmp_path):
     import torch.multiprocessing as mp
     mp.spawn(_push_timeout_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
