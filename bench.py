@@ -443,6 +443,11 @@ def main():
                            # frac counts ALGORITHMIC bytes, so XCD-L2 hits on hub rows can push it past 1; what actually crossed
                            # the fabric (PMC) over the same time is the honest HBM utilisation
                            "hbm_frac_from_traffic": (traffic / t_launch * 1e-9 / HBM_PEAK_GBS) if traffic else None}
+        if not use_dist:
+            import ctypes
+            g = ctypes.c_double()
+            if F._lib.lib().f2v_test_stream_copy(local_rank, 1 << 30, 5, ctypes.byref(g)) == 0:
+                res["roofline"]["stream_copy_GBs_on_this_box"] = g.value  # 1-GiB copy kernel, read + written bytes
     if rank == 0 and not use_dist:
         extra = {}
         for b in [int(x) for x in args.extra_batches.split(",") if x]:

@@ -74,6 +74,7 @@ SIGNATURES = {
     "f2v_sm_table": (C.c_int, [f32p]),
     "f2v_test_push_attach_local": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
     "f2v_test_ipc_preflight": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint64, C.c_double]),
+    "f2v_test_stream_copy": (C.c_int, [C.c_int, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
     "f2v_test_gather_calibration": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32]),
     "f2v_test_wave_reduce": (C.c_int, [C.c_int, f32p, C.c_uint32, C.c_uint32, f32p]),
 }

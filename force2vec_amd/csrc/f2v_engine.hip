@@ -1703,6 +1703,36 @@ int f2v_test_ipc_preflight(int device, uint32_t rank, uint32_t world, const char
     return F2V_OK;
 }
 
+// Streaming-copy ceiling of this card: `reps` copies of `bytes` (read + written = 2*bytes each), best rate in GB/s.
+int f2v_test_stream_copy(int device, uint64_t bytes, uint32_t reps, double *gbps_out) {
+    if (!gbps_out || bytes < 4096 || reps == 0) return fail(F2V_EINVAL, "f2v_test_stream_copy: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(F2V_ENODEV, "no such HIP device");
+    HIPC(hipSetDevice(device));
+    float4 *a = nullptr, *b = nullptr;
+    HIPC(hipMalloc((void **)&a, bytes));
+    HIPC(hipMalloc((void **)&b, bytes));
+    HIPC(hipMemset(a, 1, bytes));
+    HIPC(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    HIPC(hipEventCreate(&e0));
+    HIPC(hipEventCreate(&e1));
+    double best = 0.0;
+    for (uint32_t r = 0; r < reps + 2; r++) {
+        HIPC(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(stream_copy_kernel, dim3(8192), dim3(256), 0, 0, a, b, bytes / 16);
+        HIPC(hipEventRecord(e1, 0));
+        HIPC(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIPC(hipEventElapsedTime(&ms, e0, e1));
+        if (r >= 2 && ms > 0.f) best = std::max(best, 2.0 * (double)bytes / (ms * 1e-3) * 1e-9);
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(a); (void)hipFree(b);
+    *gbps_out = best;
+    return F2V_OK;
+}
+
 int f2v_test_wave_reduce(int device, const float *in, uint32_t rows, uint32_t width, float *out) {
     if (!in || !out || width == 0 || width > 512) return fail(F2V_EINVAL, "f2v_test_wave_reduce: bad argument");
     int ndev = 0;

@@ -1068,6 +1068,12 @@ __global__ void preflight_write_kernel(const PreflightArgs a) {
     __hip_atomic_store(f + a.self, (unsigned long long)a.value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// On-box streaming ceiling: dst = src, 16 bytes per lane, grid-stride
+__global__ __launch_bounds__(256) void stream_copy_kernel(const float4 *src, float4 *dst, uint64_t n4) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n4; k += stride) dst[k] = src[k];
+}
+
 // Self-test of the reduction order: out[r] = tree sum of in[r*width .. +width)
 __global__ void wave_reduce_test_kernel(const float *in, uint32_t rows, uint32_t width, float *out) {
     const uint32_t lane = threadIdx.x & 63u;

@@ -239,6 +239,8 @@ int f2v_test_push_attach_local(f2v_handle h, uint32_t rank, uint32_t world, cons
  * `world` processes that meet through files in `dir`, remote stores from a kernel), for a throw-away process to run
  * before the real engines exist: a mapping call that never returns or a faulting remote store then costs only it. */
 int f2v_test_ipc_preflight(int device, uint32_t rank, uint32_t world, const char *dir, uint64_t bytes, double timeout_s);
+/* On-box streaming-copy ceiling (read + written bytes per second of a 16-byte-per-lane copy kernel, best of `reps`). */
+int f2v_test_stream_copy(int device, uint64_t bytes, uint32_t reps, double *gbps_out);
 /* PMC calibration: `reps` launches that each gather `rows` distinct 512-byte rows exactly once with
  * the step kernel's access pattern (known HBM read volume rows*516 bytes per launch). */
 int f2v_test_gather_calibration(int device, uint32_t rows, uint32_t reps);
