@@ -123,6 +123,17 @@ def cpu_baseline(args):
     return {"value": nnz / dt, "unit": "edges/s", "cores": 1, "kind": "port", "sample": sample + "; oracle/f2v_oracle.c, 1 epoch in %.2fs" % dt}
 
 
+def kernel_name(args, pushing):
+    """The step kernel a run of this shape launches (force2vec_amd/csrc/f2v_engine.hip launch_step)."""
+    if args.dim % 4 or args.dim > 256:
+        return "f2v::step_kernel"
+    w = 16
+    while w < args.dim:
+        w <<= 1
+    return "f2v::qstep_kernel<%d, %d, %d, %d, %s, %s>" % (5 if args.option in (5, 8, 11) else 6, min(16, w // 4), max(1, w // 64), 4 if w >= 128 else 8,
+                                                          "true" if pushing else "false", "true" if w == args.dim else "false")
+
+
 def run_ref(O, mtx, td, option, iters, args, cores, avx512):
     exe = O.ref_binary(avx512)
     cmd = [exe, "-input", mtx, "-output", "/nonexistent_dir_so_no_embd_is_written/", "-iter", str(iters), "-batch", str(args.batch),
@@ -440,7 +451,7 @@ def main():
             except Exception:
                 pass
         res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": traffic, "kernel": ("f2v::qstep_kernel<%d, %d, %d, %d, %s>" % (5 if args.option in (5, 8, 11) else 6, min(16, args.dim // 4), max(1, args.dim // 64), 4 if args.dim >= 128 else 8, "true" if (use_dist and world > 1 and state["exchange"] == "push" and eng.get_param("push_fused")) else "false")) if args.dim in (16, 32, 64, 128, 256) else "f2v::step_kernel", "algorithmic_bytes_per_launch": per_launch,
+                           "traffic": traffic, "kernel": kernel_name(args, use_dist and world > 1 and state["exchange"] == "push" and eng.get_param("push_fused")), "algorithmic_bytes_per_launch": per_launch,
                            "avg_launch_us": t_launch * 1e6, "launches": st["step_launches"],
                            # frac counts ALGORITHMIC bytes, so XCD-L2 hits on hub rows can push it past 1; what actually crossed
                            # the fabric (PMC) over the same time is the honest HBM utilisation

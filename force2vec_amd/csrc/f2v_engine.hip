@@ -78,7 +78,7 @@ struct f2v_ctx {
     // work-item plans (one per distinct launch: row range x neighbour source), see plan_for()
     uint32_t chunk = 64, fanin = 32;
     bool chunk_auto = true;  // f2v_train / "hub_chunk_for_batch" pick the chunk from the batch size
-    bool use_quarter = true;  // quarter-wave kernel when D is 64, 128 or 256
+    bool use_quarter = true;  // sub-wave kernel when D is a multiple of 4 up to 256
     std::map<std::tuple<uint32_t, uint32_t, int>, Plan> plans;
     std::vector<Item> h_items;
     std::vector<FinItem> h_hubs;
@@ -151,10 +151,19 @@ void drop_plans(f2v_ctx *c) {
     c->d_items_valid = c->d_hubs_valid = 0;
 }
 
+// Width of the sub-wave layout that serves this D -- the smallest of 16, 32, 64, 128, 256 that holds it, for any D that
+// is a multiple of 4 (rows then stay 16-byte aligned; dims past D are the tree's zero padding) -- or 0: generic layout.
+uint32_t subwave_width(const f2v_ctx *c) {
+    if (!c->use_quarter || c->D % 4u != 0u || c->D > 256u) return 0u;
+    uint32_t w = 16;
+    while (w < c->D) w <<= 1;
+    return w;
+}
+
 // items one workgroup of the step kernel covers, and tree nodes one workgroup covers (= its wavefronts)
 uint32_t items_per_block(const f2v_ctx *c) {
-    const bool quarter = c->use_quarter && (c->D == 16 || c->D == 32 || c->D == 64 || c->D == 128 || c->D == 256);
-    const uint32_t per_wave = !quarter ? 1u : (c->D == 16 ? 16u : c->D == 32 ? 8u : 4u);
+    const uint32_t w = subwave_width(c);
+    const uint32_t per_wave = !w ? 1u : (w == 16 ? 16u : w == 32 ? 8u : 4u);
     return per_wave * (uint32_t)c->waves_per_block;
 }
 
@@ -461,9 +470,10 @@ int launch_step(f2v_ctx *c, int math, uint32_t batch_lo, uint32_t batch_hi, uint
     if (push) fill_targets(c, a.push, c->cur ^ 1, batch_lo, push_masks);
 
     const uint32_t wpb = (uint32_t)c->waves_per_block;
-    // sub-wave layout when D is 16, 32, 64, 128 or 256: 16, 8 or 4 work items per wavefront
-    const bool quarter = c->use_quarter && (c->D == 16 || c->D == 32 || c->D == 64 || c->D == 128 || c->D == 256);
-    const uint32_t per_wave = !quarter ? 1u : (c->D == 16 ? 16u : c->D == 32 ? 8u : 4u);
+    // sub-wave layout when D is a multiple of 4 up to 256: 16, 8 or 4 work items per wavefront
+    const uint32_t width = subwave_width(c);
+    const bool quarter = width != 0, full = width == c->D;
+    const uint32_t per_wave = !quarter ? 1u : (width == 16 ? 16u : width == 32 ? 8u : 4u);
     const uint32_t waves = (plan.n_items + per_wave - 1) / per_wave;
     uint32_t blocks = (waves + wpb - 1) / wpb;  // 0 when this rank has no row of the batch
     a.step_blocks = blocks;
@@ -483,16 +493,17 @@ int launch_step(f2v_ctx *c, int math, uint32_t batch_lo, uint32_t batch_hi, uint
     if (blocks == 0) {
         // nothing to compute here; the range bookkeeping below still advances
     } else if (quarter) {
-#define F2V_Q(OPT, LPI, NB, U)                                                                                              \
-    do {                                                                                                                    \
-        if (push) hipLaunchKernelGGL((qstep_kernel<OPT, LPI, NB, U, true>), dim3(blocks), dim3(64 * wpb), 0, c->stream, a); \
-        else hipLaunchKernelGGL((qstep_kernel<OPT, LPI, NB, U, false>), dim3(blocks), dim3(64 * wpb), 0, c->stream, a);     \
+#define F2V_Q2(OPT, LPI, NB, U, PUSH, FULL) hipLaunchKernelGGL((qstep_kernel<OPT, LPI, NB, U, PUSH, FULL>), dim3(blocks), dim3(64 * wpb), 0, c->stream, a)
+#define F2V_Q(OPT, LPI, NB, U)                                                              \
+    do {                                                                                    \
+        if (push) { if (full) F2V_Q2(OPT, LPI, NB, U, true, true); else F2V_Q2(OPT, LPI, NB, U, true, false); }    \
+        else { if (full) F2V_Q2(OPT, LPI, NB, U, false, true); else F2V_Q2(OPT, LPI, NB, U, false, false); }       \
     } while (0)
         // rows in flight per item: 4 at D = 128 (90 VGPRs, 5 waves/SIMD; 8 is selectable and measured 3-9 % slower
         // on RMAT-20: 116 VGPRs, 4 waves/SIMD) and at D = 256; 8 where a row is a single dwordx4 per lane (D <= 64)
         const bool u8 = (c->rows_in_flight == 8);
         const int o = (math == 5) ? 5 : 6;
-        switch (c->D) {
+        switch (width) {
             case 16: if (o == 5) F2V_Q(5, 4, 1, 8); else F2V_Q(6, 4, 1, 8); break;
             case 32: if (o == 5) F2V_Q(5, 8, 1, 8); else F2V_Q(6, 8, 1, 8); break;
             case 64: if (o == 5) F2V_Q(5, 16, 1, 8); else F2V_Q(6, 16, 1, 8); break;
@@ -503,6 +514,7 @@ int launch_step(f2v_ctx *c, int math, uint32_t batch_lo, uint32_t batch_hi, uint
             default: if (o == 5) F2V_Q(5, 16, 4, 4); else F2V_Q(6, 16, 4, 4); break;
         }
 #undef F2V_Q
+#undef F2V_Q2
     } else {
         rc = dispatch_layout(c, [&](auto V, auto E) {
             constexpr int VEC = decltype(V)::value;

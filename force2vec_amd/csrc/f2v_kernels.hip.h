@@ -17,8 +17,9 @@
 //   step_kernel  <OPT,VEC,EXACT>  any D <= 512: one item per wavefront, lane l owns dims
 //                                 [l*VEC, l*VEC+VEC); butterfly = DPP xor 1,2,4,8, ds_swizzle 16,
 //                                 v_readlane 32.
-//   qstep_kernel <OPT,LPI,NB,U>   D = 4*LPI*NB in {16, 32, 64, 128, 256}: 64/LPI items per wavefront on LPI
-//                                 lanes of a DPP row each; every VALU instruction serves 64/LPI pairs.
+//   qstep_kernel <OPT,LPI,NB,U>   width 4*LPI*NB in {16, 32, 64, 128, 256}, D = the width or any smaller multiple
+//                                 of 4: 64/LPI items per wavefront on LPI lanes of a DPP row each; every VALU
+//                                 instruction serves 64/LPI pairs.
 //
 // Minibatch sequencing (Jacobi inside a batch, Gauss-Seidel across batches,
 // sample/algorithms.cpp:588-639) with ONE launch per batch and no copy: the embedding matrix
@@ -642,16 +643,17 @@ __device__ __forceinline__ void pair_update_q(const float (&xi)[NB][4], const fl
     }
 }
 
-template <int LPI, int NB>
-__device__ __forceinline__ const float *row_src(const StepArgs &a, uint32_t j) {
-    return ((j - a.upd_lo) < a.upd_rows ? a.Xn : a.X) + (size_t)j * (4u * LPI * NB);
+__device__ __forceinline__ const float *row_src(const StepArgs &a, uint32_t j, uint32_t D) {
+    return ((j - a.upd_lo) < a.upd_rows ? a.Xn : a.X) + (size_t)j * D;
 }
 
 // One item's list of row ids; `cnt` is this item's length, `maxcnt` the wave's (uniform).
 // U rows per item are in flight before the first interaction is evaluated; the ids of the next group are
 // fetched one group ahead.
-template <int OPT, int LPI, int NB, bool NEG, int U>
-__device__ __forceinline__ void qprocess(const StepArgs &a, const uint32_t *ids, uint32_t cnt, uint32_t maxcnt, uint32_t t,
+// FULL: D == 4*LPI*NB.  Otherwise D is any smaller multiple of 4 (rows stay 16-byte aligned): lane t's block b is live
+// iff 4*LPI*b + 4t < D, dead pieces read as zero -- the zero padding of the canonical tree -- and are never stored.
+template <int OPT, int LPI, int NB, bool NEG, int U, bool FULL>
+__device__ __forceinline__ void qprocess(const StepArgs &a, const uint32_t *ids, uint32_t cnt, uint32_t maxcnt, uint32_t t, uint32_t D,
                                          const float (&xi)[NB][4], float (&Y)[NB][4], double c0, const float *table) {
     uint32_t j[U];
 #pragma unroll
@@ -661,9 +663,12 @@ __device__ __forceinline__ void qprocess(const StepArgs &a, const uint32_t *ids,
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (g + u < cnt) {
-                const float *src = row_src<LPI, NB>(a, j[u]) + t * 4;
+                const float *src = row_src(a, j[u], D) + t * 4;
 #pragma unroll
-                for (int b = 0; b < NB; ++b) xj[u][b] = *reinterpret_cast<const float4 *>(src + 4 * LPI * b);
+                for (int b = 0; b < NB; ++b) {
+                    if (FULL || 4u * LPI * b + 4u * t < D) xj[u][b] = *reinterpret_cast<const float4 *>(src + 4 * LPI * b);
+                    else xj[u][b] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
         }
 #pragma unroll
@@ -687,22 +692,23 @@ __device__ __forceinline__ uint32_t wave_max_of_items(uint32_t v) {
     return m;
 }
 
-template <int OPT, int LPI, int NB, int U, bool PUSH = false>
+template <int OPT, int LPI, int NB, int U, bool PUSH = false, bool FULL = true>
 __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
-    constexpr uint32_t D = 4u * LPI * NB, IPW = 64u / LPI;  // dims; items per wavefront
+    constexpr uint32_t DP = 4u * LPI * NB, IPW = 64u / LPI;  // padded dims (the tree's width); items per wavefront
+    const uint32_t D = FULL ? DP : a.D;                       // live dims = row stride
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t t = lane & (LPI - 1u), q = lane / LPI;
     const uint32_t wpb = blockDim.x >> 6;
     if (blockIdx.x >= a.step_blocks) {
         // the tail of the grid: one wavefront per node of the combine trees of this launch's hub rows; every node
         // waits for the partial sums it adds (hub pieces below announce theirs through the same flags)
-        constexpr int FVEC = D >= 64u ? (int)(D / 64u) : 1;
+        constexpr int FVEC = DP >= 64u ? (int)(DP / 64u) : 1;
         FinalizeTreeArgs ft;
         ft.f.X = a.X; ft.f.partials = a.partials; ft.f.Xn = a.Xn; ft.f.items = a.fin_items; ft.f.n_items = a.fin_n; ft.f.D = D;
         ft.f.push = a.push;
         ft.ready = a.ready; ft.err = a.err; ft.timeout_ticks = a.timeout_ticks; ft.seq = a.seq; ft.first_dep = 0u;
         const uint32_t node = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x - a.step_blocks) * wpb + (threadIdx.x >> 6)));
-        finalize_tree_node<OPT, FVEC, (D % 64u == 0u)>(ft, node, lane);
+        finalize_tree_node<OPT, FVEC, (FULL && DP % 64u == 0u)>(ft, node, lane);
         return;
     }
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + (threadIdx.x >> 6)));
@@ -712,7 +718,7 @@ __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
     // the repulsive interactions read them at LDS latency.  All lane groups of a wave read the same 16-byte
     // slots (broadcast), consecutive lanes consecutive slots: conflict-free.
     constexpr uint32_t kLdsSamples = 8;
-    __shared__ float4 smp[kLdsSamples][D / 4];
+    __shared__ float4 smp[kLdsSamples][DP / 4];
     const bool lds_samples = !a.bs_mode && a.ns <= kLdsSamples;
     // options 6/7: the 8-KiB sigmoid table is looked up once per interaction, in the middle of the dependent chain
     // dot product -> sigma -> update; from LDS that lookup costs ~64 cycles instead of an L1/L2 round trip
@@ -721,9 +727,10 @@ __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
         for (uint32_t k = threadIdx.x; k < 2048u; k += blockDim.x) sm_lds[k] = a.sm_table[k];
     }
     if (lds_samples) {
-        for (uint32_t k = threadIdx.x; k < a.ns * (D / 4); k += blockDim.x) {
-            const uint32_t sidx = k / (D / 4), c4 = k % (D / 4);
-            smp[sidx][c4] = reinterpret_cast<const float4 *>(row_src<LPI, NB>(a, a.sample_ids[sidx]))[c4];
+        for (uint32_t k = threadIdx.x; k < a.ns * (DP / 4); k += blockDim.x) {
+            const uint32_t sidx = k / (DP / 4), c4 = k % (DP / 4);
+            smp[sidx][c4] = (FULL || 4u * c4 < D) ? reinterpret_cast<const float4 *>(row_src(a, a.sample_ids[sidx], D))[c4]
+                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     if (lds_samples || OPT != 5) __syncthreads();
@@ -747,7 +754,7 @@ __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
         const float *src = a.X + (size_t)row * D + t * 4;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const float4 v = *reinterpret_cast<const float4 *>(src + 4 * LPI * b);
+            const float4 v = (FULL || 4u * LPI * b + 4u * t < D) ? *reinterpret_cast<const float4 *>(src + 4 * LPI * b) : make_float4(0.f, 0.f, 0.f, 0.f);
             xi[b][0] = v.x; xi[b][1] = v.y; xi[b][2] = v.z; xi[b][3] = v.w;
         }
     }
@@ -767,7 +774,7 @@ __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
         c0 = (double)(a.lr * degi);
     }
 
-    qprocess<OPT, LPI, NB, false, U>(a, a.nbr_ids + it.nb, it.cnt, wave_max_of_items<LPI>(it.cnt), t, xi, Y, c0, table);
+    qprocess<OPT, LPI, NB, false, U, FULL>(a, a.nbr_ids + it.nb, it.cnt, wave_max_of_items<LPI>(it.cnt), t, D, xi, Y, c0, table);
     if (lds_samples) {
         if (active && last_chunk) {
             for (uint32_t sidx = 0; sidx < a.ns; ++sidx) {
@@ -780,7 +787,7 @@ __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
     } else {
         const uint32_t scnt = (active && last_chunk) ? a.ns : 0u;
         const uint32_t sbase = a.bs_mode ? (row - a.batch_lo) : 0u;
-        qprocess<OPT, LPI, NB, true, U>(a, a.sample_ids + sbase, scnt, wave_max_of_items<LPI>(scnt), t, xi, Y, c0, table);
+        qprocess<OPT, LPI, NB, true, U, FULL>(a, a.sample_ids + sbase, scnt, wave_max_of_items<LPI>(scnt), t, D, xi, Y, c0, table);
     }
 
     if (active) {
@@ -792,6 +799,7 @@ __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
                 v[b] = make_float4(xi[b][0] + Y[b][0], xi[b][1] + Y[b][1], xi[b][2] + Y[b][2], xi[b][3] + Y[b][3]);  // algorithms.cpp:636
             else
                 v[b] = make_float4(Y[b][0], Y[b][1], Y[b][2], Y[b][3]);
+            if (!FULL && !(4u * LPI * b + 4u * t < D)) continue;
             if (partial && a.fin_items) store16_agent(out + 4 * LPI * b, v[b]);  // a tree node of this grid reads it
             else *reinterpret_cast<float4 *>(out + 4 * LPI * b) = v[b];
         }
@@ -806,7 +814,8 @@ __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
                     if (m & (1u << q)) {
                         float *dst = a.push.peer[q] + (size_t)(row - a.push.row_base) * D + t * 4;
 #pragma unroll
-                        for (int b = 0; b < NB; ++b) store16_system(dst + 4 * LPI * b, v[b]);
+                        for (int b = 0; b < NB; ++b)
+                            if (FULL || 4u * LPI * b + 4u * t < D) store16_system(dst + 4 * LPI * b, v[b]);
                     }
                 }
             }

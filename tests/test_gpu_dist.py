@@ -101,7 +101,8 @@ def _single_twice(case):
 
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("case", [("cora.mtx", 5, 3, 256, 128, 0), ("cora.mtx", 6, 2, 300, 64, 0), ("pubmed.mtx", 5, 2, 4096, 128, 0),
-                                  ("karate.mtx", 7, 3, 16, 64, 0), ("cora.mtx", 5, 2, 300, 100, 1), ("citeseer.mtx", 11, 2, 1000, 32, 0)])
+                                  ("karate.mtx", 7, 3, 16, 64, 0), ("cora.mtx", 5, 2, 300, 100, 1), ("citeseer.mtx", 11, 2, 1000, 32, 0),
+                                  ("cora.mtx", 6, 2, 256, 66, 0)])
 def test_push_exchange_between_processes_sharing_the_gpu(case, world, tmp_path):
     """f2v_train_sharded: every rank maps its peers' matrices and flags through HIP IPC, pushes its new rows into
     the peers that read them and passes the device-side flag barrier -- here between processes on ONE card (the

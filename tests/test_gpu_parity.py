@@ -278,10 +278,12 @@ def test_train_bit_exact_vs_oracle_and_close_to_reference(F, graph, option, iter
     algo.engine.close()
 
 
-@pytest.mark.parametrize("option,dim", [(5, 16), (5, 32), (5, 64), (5, 128), (5, 256), (6, 16), (6, 32), (6, 128), (6, 256), (7, 32), (7, 64)])
+@pytest.mark.parametrize("option,dim", [(5, 16), (5, 32), (5, 64), (5, 128), (5, 256), (6, 16), (6, 32), (6, 128), (6, 256), (7, 32), (7, 64),
+                                        # D below the layout's width (any multiple of 4): dead lanes are the tree's zero padding
+                                        (5, 4), (5, 12), (5, 20), (5, 48), (5, 100), (5, 200), (5, 252), (6, 8), (6, 36), (6, 100), (6, 132), (7, 24), (7, 96)])
 def test_quarter_wave_and_generic_layouts_agree(F, option, dim):
-    """The sub-wave kernel (16 / 8 / 4 items per wavefront at D = 16 / 32 / 64..256) and the generic one (1 item per
-    wavefront) implement the same canonical reduction tree: identical bits."""
+    """The sub-wave kernel (16 / 8 / 4 items per wavefront at widths 16 / 32 / 64..256; D = any multiple of 4 up to its
+    width) and the generic one (1 item per wavefront) implement the same canonical reduction tree: identical bits."""
     rowptr, colids = random_graph(500, 10, seed=3, hubs=((2, 300), (400, 77)))
     res = []
     for q in (1, 0):
