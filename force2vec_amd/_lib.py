@@ -94,11 +94,14 @@ class F2VError(RuntimeError):
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("F2V_LIBRARY", LIB_PATH)  # A/B runs of two builds of the library
+        if not os.path.exists(path):
             raise ImportError("%s is missing: build it with `make` (hipcc --offload-arch=gfx950); "
-                              "force2vec_amd has no fallback implementation" % LIB_PATH)
-        L = C.CDLL(LIB_PATH)
+                              "force2vec_amd has no fallback implementation" % path)
+        L = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
+            if path != LIB_PATH and not hasattr(L, name):
+                continue  # an older build in an A/B run
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args

@@ -216,21 +216,28 @@ const Plan &plan_for(f2v_ctx *c, uint32_t row_lo, uint32_t row_hi, bool walk) {
     p.n_chunks = slots;
     std::vector<Item> items;
     items.reserve(whole.size() + slots + 64);
-    const Item pad_item{0, 0, 0, kItemPad};
+    // inert filler: an empty piece of row `row_lo` whose (zero) partial sum goes to a slot of its own that no node reads --
+    // the kernels need no special case for it
+    Item pad_item{row_lo, 0, 0, kItemPartial};
+    bool padded = false;
     const FinItem pad_node{0, 0, kFinToStage, 0};
     std::stable_sort(whole.begin(), whole.end(), [](const Item &x, const Item &y) { return x.cnt > y.cnt; });
     if (!cur.empty()) {
         // Lowest tree level first: one node per GROUP of `fanin` consecutive pieces of a hub.  A group -- its pieces and
-        // its node -- gets a class, groups take the classes in turn (a giant hub thus spreads over all XCDs).
+        // its node -- gets the class that has been given the fewest neighbours so far (a giant hub thus spreads over all XCDs).
         std::vector<Item> queue[kXcds];
         std::vector<FinItem> nq[kXcds];
-        uint32_t next_cls = 0;
+        uint64_t load[kXcds] = {};  // neighbours given to every class so far: a group goes to the lightest one
         for (const Node &nd : cur) {
             const uint32_t rp = c->rowptr[nd.row], deg = c->rowptr[nd.row + 1] - rp;
             const uint32_t G = c->fanin < 2 ? nd.n : c->fanin;
             const uint32_t nout = (nd.n + G - 1) / G;
             for (uint32_t o = 0; o < nout; o++) {
-                const uint32_t cls = next_cls++ % kXcds, k0 = o * G, k1 = std::min(nd.n, k0 + G);
+                const uint32_t k0 = o * G, k1 = std::min(nd.n, k0 + G);
+                uint32_t cls = 0;
+                for (uint32_t k = 1; k < kXcds; k++)
+                    if (load[k] < load[cls]) cls = k;
+                load[cls] += std::min(deg, k1 * c->chunk) - k0 * c->chunk;
                 for (uint32_t k = k0; k < k1; k++) {
                     const uint32_t b = k * c->chunk, e = std::min(deg, b + c->chunk);
                     queue[cls].push_back(Item{nd.row, rp + b, e - b, kItemPartial | (k == 0 ? kItemFirst : 0u) | (k == nd.n - 1 ? kItemLast : 0u) | (nd.in_slot + k)});
@@ -243,22 +250,24 @@ const Plan &plan_for(f2v_ctx *c, uint32_t row_lo, uint32_t row_hi, bool walk) {
             }
         }
         for (auto &q : queue) std::stable_sort(q.begin(), q.end(), [](const Item &x, const Item &y) { return x.cnt > y.cnt; });
-        // one workgroup per class per round; a class that has run out of pieces hands its workgroups to whole rows
+        // One workgroup per class per round, longest first overall: a class's workgroup takes its own pieces as long as
+        // they are at least as long as the longest whole row still waiting (whole rows may run anywhere), else whole rows.
         size_t pos[kXcds] = {}, wpos = 0;
         for (bool more = true; more;) {
             more = false;
             for (uint32_t k = 0; k < kXcds; k++) {
                 for (uint32_t j = 0; j < ipb; j++) {
-                    if (pos[k] < queue[k].size()) items.push_back(queue[k][pos[k]++]);
-                    else if (wpos < whole.size()) items.push_back(whole[wpos++]);
-                    else items.push_back(pad_item);
+                    const bool mine = pos[k] < queue[k].size(), any = wpos < whole.size();
+                    if (mine && (!any || queue[k][pos[k]].cnt >= whole[wpos].cnt)) items.push_back(queue[k][pos[k]++]);
+                    else if (any) items.push_back(whole[wpos++]);
+                    else { items.push_back(pad_item); padded = true; }
                 }
                 more = more || pos[k] < queue[k].size();
             }
         }
         items.insert(items.end(), whole.begin() + wpos, whole.end());
         // the nodes' workgroups follow the items': their first one must again be a multiple of 8
-        while (items.size() % ((size_t)kXcds * ipb) != 0) items.push_back(pad_item);
+        while (items.size() % ((size_t)kXcds * ipb) != 0) { items.push_back(pad_item); padded = true; }
         p.fin_off[0] = c->h_hubs.size();
         size_t npos[kXcds] = {};
         for (bool more = true; more;) {
@@ -274,6 +283,7 @@ const Plan &plan_for(f2v_ctx *c, uint32_t row_lo, uint32_t row_hi, bool walk) {
     } else {
         items.insert(items.end(), whole.begin(), whole.end());
     }
+    const size_t items_at = c->h_items.size();
     c->h_items.insert(c->h_items.end(), items.begin(), items.end());
     p.n_items = (uint32_t)items.size();
     // upper levels: groups of `fanin` sums are added in order until one is left.  Their nodes are few (1/fanin of the
@@ -296,6 +306,11 @@ const Plan &plan_for(f2v_ctx *c, uint32_t row_lo, uint32_t row_hi, bool walk) {
         p.fin_cnt[p.n_levels] = (uint32_t)(c->h_hubs.size() - p.fin_off[p.n_levels]);
         p.n_levels++;
         cur.swap(nxt);
+    }
+    if (padded) {  // the fillers' slot: one past every slot a node reads
+        for (size_t k = items_at; k < items_at + p.n_items; k++)
+            if (c->h_items[k].cnt == 0 && c->h_items[k].flags == kItemPartial) c->h_items[k].flags = kItemPartial | slots;
+        slots++;
     }
     p.n_slots = slots;
     c->max_slots = std::max<size_t>(c->max_slots, slots);

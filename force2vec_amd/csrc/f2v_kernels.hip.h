@@ -56,7 +56,6 @@ struct Item {
 constexpr uint32_t kItemPartial = 1u << 31;  // store the force sum to partials[slot] (hub chunk), not the new row
 constexpr uint32_t kItemFirst = 1u << 30;    // first chunk of its row (sigmoid: accumulates onto x_i)
 constexpr uint32_t kItemLast = 1u << 29;     // last chunk of its row: also takes the negative samples
-constexpr uint32_t kItemPad = 1u << 28;      // inert: fills a workgroup so that the next hub piece lands on the right XCD
 constexpr uint32_t kItemSlotMask = (1u << 28) - 1;
 
 // One node of a hub row's combine tree: add partial rows [in_slot, in_slot+n) in order.
@@ -366,7 +365,6 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
     if (w >= a.n_items) return;
 
     const Item it = a.items[w];
-    if (it.flags & kItemPad) return;
     const uint32_t row = it.row;
     const bool partial = (it.flags & kItemPartial) != 0;
     const bool first_chunk = (it.flags & kItemFirst) != 0;
@@ -739,11 +737,10 @@ __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
 
     // this item's lanes (lane groups past the end of the list idle with cnt = 0)
     const uint32_t idx = IPW * w + q;
-    bool active = idx < a.n_items;
+    const bool active = idx < a.n_items;
     Item it;
     if (active) it = a.items[idx];
     else { it.row = 0; it.nb = 0; it.cnt = 0; it.flags = 0; }
-    if (it.flags & kItemPad) { active = false; it.flags = 0; }
     const uint32_t row = it.row;
     const bool partial = (it.flags & kItemPartial) != 0;
     const bool first_chunk = (it.flags & kItemFirst) != 0;
