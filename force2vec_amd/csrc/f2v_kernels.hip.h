@@ -509,7 +509,8 @@ __device__ __forceinline__ void finalize_tree_node(const FinalizeTreeArgs &a, ui
     float Y[VEC];
     if (w >= a.first_dep) {
         const unsigned long long t0 = wall_clock64();
-        for (uint32_t c = lane; c < h.n; c += 64u) {
+        const bool lost = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;  // an earlier launch gave up: no more waiting
+        for (uint32_t c = lane; c < h.n && !lost; c += 64u) {
             uint32_t seen;
             while ((seen = __hip_atomic_load(a.ready + h.in_slot + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != a.seq) {
                 __builtin_amdgcn_s_sleep(1);
@@ -967,8 +968,10 @@ __global__ __launch_bounds__(64) void xgmi_barrier_kernel(const BarrierArgs b) {
             if ((uint32_t)q == r) theirs = b.peer_flags[q];
         __hip_atomic_store(theirs + b.self, b.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         const unsigned long long t0 = wall_clock64();
+        // once a wait has given up the run is lost anyway: later barriers do not wait again (one time-out, not one per minibatch)
+        const bool lost = __hip_atomic_load(b.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
         // relaxed system-scope loads go to memory every time without invalidating this XCD's L2 on every poll
-        while (__hip_atomic_load(b.flags + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < b.seq) {
+        while (!lost && __hip_atomic_load(b.flags + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < b.seq) {
             __builtin_amdgcn_s_sleep(4);
             if (wall_clock64() - t0 > b.timeout_ticks) {
                 __hip_atomic_store(b.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
