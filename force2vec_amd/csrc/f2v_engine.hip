@@ -906,12 +906,37 @@ int f2v_init_embeddings(f2v_handle c, int kind) {
         c->have_x = true;
         return F2V_OK;
     }
-    std::unique_ptr<float[]> x(new float[total]);  // not value-initialised: the fill threads are the first to touch it
-    init_embeddings_host(c->rng, x.get(), total, kind);
     HIPC(hipStreamSynchronize(c->stream));
     c->pending = false;
     c->upd_lo = c->upd_hi = 0;
-    HIPC(hipMemcpy(c->d_X[c->cur], x.get(), total * sizeof(float), hipMemcpyHostToDevice));
+    constexpr size_t kPiece = (size_t)64 << 20;  // floats: 256 MiB
+    if (total >= 2 * kPiece) {
+        // Large matrices (8 GiB at RMAT-24): the one serial rand() stream is filled piece by piece into two pinned staging
+        // buffers by the fill threads (jump-ahead states, bit-identical to the serial stream) while the previous piece
+        // travels to HBM -- the pageable-memory copy of the whole matrix used to take longer than generating it.
+        float *stage[2] = {nullptr, nullptr};
+        hipEvent_t done[2];
+        bool used[2] = {false, false};
+        for (int k = 0; k < 2; k++) {
+            HIPC(hipHostMalloc((void **)&stage[k], kPiece * sizeof(float), hipHostMallocDefault));
+            HIPC(hipEventCreateWithFlags(&done[k], hipEventDisableTiming));
+        }
+        int k = 0;
+        for (size_t off = 0; off < total; off += kPiece, k ^= 1) {
+            const size_t len = std::min(kPiece, total - off);
+            if (used[k]) HIPC(hipEventSynchronize(done[k]));
+            init_embeddings_host(c->rng, stage[k], len, kind);
+            HIPC(hipMemcpyAsync(c->d_X[c->cur] + off, stage[k], len * sizeof(float), hipMemcpyHostToDevice, c->stream));
+            HIPC(hipEventRecord(done[k], c->stream));
+            used[k] = true;
+        }
+        HIPC(hipStreamSynchronize(c->stream));
+        for (int j = 0; j < 2; j++) { (void)hipEventDestroy(done[j]); (void)hipHostFree(stage[j]); }
+    } else {
+        std::unique_ptr<float[]> x(new float[total]);  // not value-initialised: the fill threads are the first to touch it
+        init_embeddings_host(c->rng, x.get(), total, kind);
+        HIPC(hipMemcpy(c->d_X[c->cur], x.get(), total * sizeof(float), hipMemcpyHostToDevice));
+    }
     c->have_x = true;
     return F2V_OK;
 }
