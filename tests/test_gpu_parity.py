@@ -564,3 +564,22 @@ def test_cora_link_prediction_matches_reference(F):
     for g, r in zip(got, ref):
         assert abs(g - r) <= 0.5, (got, ref)
     algo.engine.close()
+
+
+def test_self_test_hooks_run(F, tmp_path):
+    """The measurement / rehearsal hooks bench.py relies on: streaming-copy ceiling, single-rank IPC preflight."""
+    import ctypes
+    g = ctypes.c_double()
+    F._lib.check(F._lib.lib().f2v_test_stream_copy(0, 64 << 20, 2, ctypes.byref(g)))
+    assert 100.0 < g.value < 20000.0  # GB/s, read + written
+    F._lib.check(F._lib.lib().f2v_test_ipc_preflight(0, 0, 1, str(tmp_path).encode(), 1 << 20, 5.0))
+    assert F._lib.lib().f2v_test_ipc_preflight(0, 1, 1, str(tmp_path).encode(), 1 << 20, 5.0) != 0  # rank outside the world
+
+
+def test_two_ranks_ipc_preflight_children(tmp_path):
+    """tools/ipc_preflight.py as bench.py starts it: two throw-away processes map each other's buffers and flags through HIP
+    IPC, store into them from a kernel and verify what arrived."""
+    import sys
+    exe = [sys.executable, os.path.join(ROOT, "tools", "ipc_preflight.py")]
+    ps = [subprocess.Popen(exe + ["0", str(r), "2", str(tmp_path), str(64 << 20), "30"]) for r in range(2)]
+    assert [p.wait(timeout=120) for p in ps] == [0, 0]
