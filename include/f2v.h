@@ -156,7 +156,9 @@ int f2v_synchronize(f2v_handle h);
  * Matrices of 2 GiB and more cannot be mapped through HIP IPC (hipIpcOpenMemHandle does not return): such
  * engines exchange through a mapped landing buffer of one minibatch (two halves of at most 512 MiB) that a
  * small kernel unpacks behind the barrier -- automatically, or for any size with "push_landing" = 1 (set
- * before f2v_push_export, on every rank alike).  A minibatch must then fit one half. */
+ * before f2v_push_export, on every rank alike).  A minibatch must then fit one half.
+ * Environment, for tests: F2V_PUSH_CHAOS=<seed> makes every rank stall (drain its stream and sleep up to 3 ms) at
+ * random minibatches of f2v_train_sharded; F2V_TREE_TIMEOUT_MS bounds the waits of the combine-tree nodes (5000). */
 #define F2V_PUSH_MAX_RANKS 8
 #define F2V_PUSH_EXPORT_BYTES 256
 int f2v_push_export(f2v_handle h, void *handles_out);
