@@ -255,11 +255,49 @@ __device__ __forceinline__ void store16_agent(float *p, const float4 v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(x) : "memory");
 }
 
+// The wave's row regrouped into 16-byte pieces: every written-through store is one fabric write, and an 8-byte one
+// costs 2.7x, a 4-byte one ~6x the time per byte of a 16-byte one (MI355X_MICROARCH.md).  VEC = 2: lane pairs (xor 1),
+// the even lane holds four consecutive dims; VEC = 1: quads, lane 4k holds them.  Valid when D is a multiple of 4.
+template <int VEC>
+__device__ __forceinline__ bool gather16(const float (&in)[VEC], uint32_t lane, float4 (&out)[VEC >= 4 ? VEC / 4 : 1], uint32_t &first_dim) {
+    if constexpr (VEC >= 4) {
+#pragma unroll
+        for (int k = 0; k < VEC / 4; ++k) out[k] = make_float4(in[4 * k], in[4 * k + 1], in[4 * k + 2], in[4 * k + 3]);
+        first_dim = lane * VEC;
+        return true;
+    } else if constexpr (VEC == 2) {
+        const float o0 = dpp_mov<0xB1>(in[0]), o1 = dpp_mov<0xB1>(in[1]);  // the partner lane's pair
+        out[0] = make_float4(in[0], in[1], o0, o1);
+        first_dim = lane * 2u;
+        return (lane & 1u) == 0u;
+    } else {
+        const float a = dpp_mov<0x55>(in[0]), b = dpp_mov<0xAA>(in[0]), c = dpp_mov<0xFF>(in[0]);  // quad lanes 1, 2, 3
+        out[0] = make_float4(in[0], a, b, c);
+        first_dim = lane;
+        return (lane & 3u) == 0u;
+    }
+}
+
 // push one finished row (held by the wave, VEC values per lane) to the peers that read it
 template <int VEC, bool EXACT>
 __device__ __forceinline__ void push_row(const PushTargets &t, uint32_t row, uint32_t lane, uint32_t D, const float (&in)[VEC]) {
     const uint32_t others = ((1u << t.world) - 1u) & ~(1u << t.self);
     const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)((t.masks ? t.masks[row] : others) & others));
+    if (D % 4u == 0u) {  // rows are 16-byte aligned: 16-byte stores
+        float4 piece[VEC >= 4 ? VEC / 4 : 1];
+        uint32_t d0;
+        const bool mine = gather16<VEC>(in, lane, piece, d0) && d0 < D;
+#pragma unroll
+        for (int q = 0; q < kMaxRanks; ++q) {
+            if ((m & (1u << q)) && mine) {
+                float *dst = t.peer[q] + (size_t)(row - t.row_base) * D + d0;
+#pragma unroll
+                for (int k = 0; k < (VEC >= 4 ? VEC / 4 : 1); ++k)
+                    if (d0 + 4u * k < D) store16_system(dst + 4 * k, piece[k]);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < kMaxRanks; ++q) {
         if (m & (1u << q)) store_row_system<VEC, EXACT>(t.peer[q] + (size_t)(row - t.row_base) * D, lane, D, in);

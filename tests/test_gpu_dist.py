@@ -182,7 +182,9 @@ def _push_timeout_worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", [("cora.mtx", 5, 3, 256, 128, 0), ("pubmed.mtx", 6, 2, 4096, 128, 0), ("cora.mtx", 5, 2, 300, 100, 1)])
+@pytest.mark.parametrize("case", [("cora.mtx", 5, 3, 256, 128, 0), ("pubmed.mtx", 6, 2, 4096, 128, 0), ("cora.mtx", 5, 2, 300, 100, 1),
+                                  ("cora.mtx", 5, 2, 256, 260, 0), ("cora.mtx", 6, 2, 256, 20, 0), ("cora.mtx", 5, 2, 256, 512, 0),
+                                  ("cora.mtx", 5, 2, 256, 30, 0)])
 def test_push_exchange_with_a_separate_push_kernel(case, tmp_path):
     """ "push_fused" = 0: the same exchange with the rows copied to the peers by push_rows_kernel after the step."""
     import torch.multiprocessing as mp
