@@ -246,13 +246,15 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 // consecutive 16-byte pieces, so a 16-lane item sends whole 256-byte runs down the link
 __device__ __forceinline__ void store16_system(float *p, const float4 v) {
     const f32x4_t x = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(x) : "memory");
+    // s_nop 1 inside the statement: hipcc pads no hazards of an asm instruction, and its next instruction may otherwise
+    // overwrite the four data registers before the store has read them (cdna_hip_programming.md 5.7 item 1)
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(x) : "memory");
 }
 
 // the same written through at agent scope (sc1): visible to the other XCDs' L2s once acknowledged
 __device__ __forceinline__ void store16_agent(float *p, const float4 v) {
     const f32x4_t x = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(x) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(x) : "memory");
 }
 
 // The wave's row regrouped into 16-byte pieces: every written-through store is one fabric write, and an 8-byte one
