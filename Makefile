@@ -8,16 +8,22 @@ CSRC = force2vec_amd/csrc
 CXXFLAGS = -O3 -std=c++17 -fPIC -pthread -Iinclude -I$(CSRC) -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result
 HIPFLAGS = --offload-arch=$(ARCH) $(CXXFLAGS)
 LIB = force2vec_amd/libf2v.so
+# the same sources with the self-test hooks of include/f2v_test.h compiled in (tests/, tools/ only)
+TESTLIB = force2vec_amd/libf2v_selftest.so
+SRCS = $(CSRC)/f2v_engine.hip $(CSRC)/f2v_kernels.hip.h $(CSRC)/f2v_host.cpp $(CSRC)/f2v_internal.h include/f2v.h
 
-all: $(LIB) bin/Force2Vec
+all: $(LIB) $(TESTLIB) bin/Force2Vec
 
-$(LIB): $(CSRC)/f2v_engine.hip $(CSRC)/f2v_kernels.hip.h $(CSRC)/f2v_host.cpp $(CSRC)/f2v_internal.h include/f2v.h
+$(LIB): $(SRCS)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/f2v_engine.hip $(CSRC)/f2v_host.cpp
+
+$(TESTLIB): $(SRCS) include/f2v_test.h
+	$(HIPCC) $(HIPFLAGS) -DF2V_TEST_HOOKS -shared -o $@ $(CSRC)/f2v_engine.hip $(CSRC)/f2v_host.cpp
 
 bin/Force2Vec: $(CSRC)/cli_main.cpp $(CSRC)/algorithms.hpp include/f2v.h $(LIB)
 	mkdir -p bin
 	$(HIPCC) $(CXXFLAGS) -o $@ $(CSRC)/cli_main.cpp -Lforce2vec_amd -lf2v -Wl,-rpath,'$$ORIGIN/../force2vec_amd'
 
 clean:
-	rm -f $(LIB) bin/Force2Vec
+	rm -f $(LIB) $(TESTLIB) bin/Force2Vec
 .PHONY: all clean

@@ -460,7 +460,7 @@ def main():
         if not use_dist:
             import ctypes
             g = ctypes.c_double()
-            if F._lib.lib().f2v_test_stream_copy(local_rank, 1 << 30, 5, ctypes.byref(g)) == 0:
+            if F._lib.lib().f2v_diag_stream_copy(local_rank, 1 << 30, 5, ctypes.byref(g)) == 0:
                 res["roofline"]["stream_copy_GBs_on_this_box"] = g.value  # 1-GiB copy kernel, read + written bytes
     if rank == 0 and not use_dist:
         extra = {}

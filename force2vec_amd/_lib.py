@@ -6,6 +6,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libf2v.so")
+SELFTEST_LIB_PATH = os.path.join(HERE, "libf2v_selftest.so")
 
 F2V_OK, F2V_EINVAL, F2V_ENODEV, F2V_ENOMEM, F2V_EIO, F2V_ESTATE = 0, -1, -2, -3, -4, -5
 INIT_SYMMETRIC, INIT_UNIT = 0, 1
@@ -72,17 +73,23 @@ SIGNATURES = {
     "f2v_rng_jump": (None, [C.c_void_p, C.c_uint64]),
     "f2v_rng_fill": (C.c_int, [C.c_void_p, f32p, C.c_uint64, C.c_int]),
     "f2v_sm_table": (C.c_int, [f32p]),
+    "f2v_diag_ipc_preflight": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint64, C.c_double]),
+    "f2v_diag_stream_copy": (C.c_int, [C.c_int, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
+}
+
+# include/f2v_test.h: only in libf2v_selftest.so (the same sources built with -DF2V_TEST_HOOKS), for tests/ and tools/
+TEST_SIGNATURES = {
     "f2v_test_push_attach_local": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
-    "f2v_test_ipc_preflight": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint64, C.c_double]),
-    "f2v_test_stream_copy": (C.c_int, [C.c_int, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
     "f2v_test_gather_calibration": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32]),
     "f2v_test_wave_reduce": (C.c_int, [C.c_int, f32p, C.c_uint32, C.c_uint32, f32p]),
+    "f2v_test_withhold_flag": (C.c_int, [C.c_void_p, C.c_uint32]),
 }
 
 PUSH_EXPORT_BYTES = 256  # F2V_PUSH_EXPORT_BYTES
 PUSH_MAX_RANKS = 8       # F2V_PUSH_MAX_RANKS
 
 _lib = None
+_selftest = None
 
 
 class F2VError(RuntimeError):
@@ -109,6 +116,22 @@ def lib():
     return _lib
 
 
-def check(rc):
+def selftest_lib():
+    """The self-test build (fault injection, look-inside hooks): a library of its own, with its own handles."""
+    global _selftest
+    if _selftest is None:
+        if not os.path.exists(SELFTEST_LIB_PATH):
+            raise ImportError("%s is missing: build it with `make`" % SELFTEST_LIB_PATH)
+        L = C.CDLL(SELFTEST_LIB_PATH)
+        for table in (SIGNATURES, TEST_SIGNATURES):
+            for name, (res, args) in table.items():
+                fn = getattr(L, name)
+                fn.restype = res
+                fn.argtypes = args
+        _selftest = L
+    return _selftest
+
+
+def check(rc, L=None):
     if rc != F2V_OK:
-        raise F2VError(rc, lib().f2v_last_error().decode(errors="replace"))
+        raise F2VError(rc, (L or lib()).f2v_last_error().decode(errors="replace"))

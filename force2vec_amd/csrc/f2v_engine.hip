@@ -23,6 +23,9 @@
 #include <vector>
 
 #include "f2v.h"
+#ifdef F2V_TEST_HOOKS
+#include "f2v_test.h"
+#endif
 #include "f2v_internal.h"
 #include "f2v_kernels.hip.h"
 
@@ -71,6 +74,13 @@ struct f2v_ctx {
     float *d_X[2] = {nullptr, nullptr}, *d_partials = nullptr, *d_table = nullptr;
     uint32_t *d_ready = nullptr, *d_kerr = nullptr;  // combine-tree flags (one per partial slot), kernel error word
     uint32_t launch_seq = 0;
+    uint32_t xcc_count = 0;      // XCDs seen by the dispatch probe of f2v_create
+    bool xcc_round_robin = false;  // ... and workgroup b ran on the XCD of workgroup b mod 8
+    int64_t tree_timeout_ms = 5000;
+    uint32_t *h_kerr = nullptr;  // pinned: the kernel error words as of the last completed epoch-end copy (train_impl)
+#ifdef F2V_TEST_HOOKS
+    uint32_t test_withhold_slot = kNoSlot;
+#endif
     bool merge_fin = true, capturing = false;  // all combine-tree levels in one launch (not while a hipGraph is captured)
     int cur = 0;  // d_X[cur]: current matrix; d_X[cur^1]: receives the rows updated this epoch
     bool have_x = false, have_walks = false;
@@ -417,16 +427,27 @@ int flush_pending(f2v_ctx *c) {
     return F2V_OK;
 }
 
+// A combine-tree node's wait timed out (the words of d_kerr are in `e`): nodes that give up store nothing, so the rows
+// of the affected hub vertices were not updated from that launch on -- the embeddings are invalid and must be set again.
+// The handle stays usable: the error words are cleared and it runs one launch per tree level from now on (no in-grid waits).
+int kernel_gave_up(f2v_ctx *c, const char *where, const uint32_t *e) {
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipMemsetAsync(c->d_kerr, 0, 64, c->stream);
+    (void)hipStreamSynchronize(c->stream);
+    c->merge_fin = false;
+    c->pending = false;
+    c->upd_lo = c->upd_hi = 0;
+    c->have_x = false;
+    return fail(F2V_ESTATE, "%s: %u combine-tree waits gave up (first: node %u of %u [first dependent %u] on slot %u, flag %u, launch %u); "
+                "the embeddings are invalid from that minibatch on (set or initialise them again); this handle now runs with \"merge_finalize\" = 0",
+                where, e[1], e[2], e[6], e[7], e[3], e[4], e[5]);
+}
+
 // after a stream synchronisation: did a kernel give up a bounded wait?
 int check_kernel_err(f2v_ctx *c, const char *where) {
     uint32_t e[8] = {};
     HIPC(hipMemcpy(e, c->d_kerr, sizeof e, hipMemcpyDeviceToHost));
-    if (e[0]) {
-        (void)hipMemset(c->d_kerr, 0, sizeof e);
-        (void)hipDeviceSynchronize();
-        return fail(F2V_ESTATE, "%s: %u combine-tree waits gave up (first: node %u of %u [first dependent %u] on slot %u, flag %u, launch %u); set \"merge_finalize\" = 0",
-                    where, e[1], e[2], e[6], e[7], e[3], e[4], e[5]);
-    }
+    if (e[0]) return kernel_gave_up(c, where, e);
     return F2V_OK;
 }
 
@@ -442,15 +463,9 @@ int math_of_option(int option) {
 // Launch one minibatch step (+ hub finalisation) on the handle's stream.  d_ids: device sample ids.
 void fill_targets(const f2v_ctx *c, PushTargets &t, int which, uint32_t batch_lo, const uint32_t *d_masks);
 
-// bound of a combine-tree node's wait: 5 s of the 100 MHz wall clock (F2V_TREE_TIMEOUT_MS overrides, for experiments)
-unsigned long long tree_timeout_ticks() {
-    static const unsigned long long ticks = [] {
-        const char *e = getenv("F2V_TREE_TIMEOUT_MS");
-        const long ms = e ? atol(e) : 5000;
-        return (unsigned long long)(ms > 0 ? ms : 5000) * 100000ull;
-    }();
-    return ticks;
-}
+// bound of a combine-tree node's wait in ticks of the 100 MHz wall clock ("tree_timeout_ms", default 5 s; the
+// environment variable F2V_TREE_TIMEOUT_MS sets the default of new handles)
+unsigned long long tree_timeout_ticks(const f2v_ctx *c) { return (unsigned long long)c->tree_timeout_ms * 100000ull; }
 
 // push_masks / push: a sharded run's step -- the kernels also store every finished row into the second matrix of
 // the peers that read it (push_masks == nullptr: of every peer).
@@ -500,9 +515,12 @@ int launch_step(f2v_ctx *c, int math, uint32_t batch_lo, uint32_t batch_hi, uint
         for (int lev = 0; lev < plan.n_levels; lev++) a.fin_n += plan.fin_cnt[lev];  // the levels are stored back to back
         a.ready = c->d_ready;
         a.err = c->d_kerr;
-        a.timeout_ticks = tree_timeout_ticks();
+        a.timeout_ticks = tree_timeout_ticks(c);
         a.seq = ++c->launch_seq;
         if (a.seq == 0) a.seq = ++c->launch_seq;  // 0 is what fresh flags hold
+#ifdef F2V_TEST_HOOKS
+        a.test_withhold_slot = c->test_withhold_slot;
+#endif
         blocks += (a.fin_n + wpb - 1) / wpb;
     }
     if (blocks == 0) {
@@ -555,7 +573,7 @@ int launch_step(f2v_ctx *c, int math, uint32_t batch_lo, uint32_t batch_hi, uint
         t.f.push = a.push;
         t.ready = c->d_ready;
         t.err = c->d_kerr;
-        t.timeout_ticks = tree_timeout_ticks();
+        t.timeout_ticks = tree_timeout_ticks(c);
         t.seq = ++c->launch_seq;
         if (t.seq == 0) t.seq = ++c->launch_seq;  // 0 is what fresh flags hold
         t.first_dep = plan.fin_cnt[0];
@@ -850,6 +868,37 @@ int f2v_create(const uint32_t *rowptr, const uint32_t *colids, uint32_t n, uint6
     float table[kSmTableSize];
     sm_table_host(table);
     HIPB(hipMemcpy(c->d_table, table, sizeof table, hipMemcpyHostToDevice));
+    HIPB(hipHostMalloc((void **)&c->h_kerr, 4 * 64, hipHostMallocDefault));
+    memset(c->h_kerr, 0, 4 * 64);
+    if (const char *e = getenv("F2V_TREE_TIMEOUT_MS")) {
+        const long ms = atol(e);
+        if (ms > 0 && ms <= 600000) c->tree_timeout_ms = ms;
+    }
+    {
+        // Dispatch probe: the one-launch minibatch (combine-tree nodes waiting inside the step kernel's grid) counts on
+        // 8 XCDs taking workgroups round robin.  Checked here, on this device as this process sees it; if it does not
+        // hold the handle starts with "merge_finalize" = 0 (one launch per tree level: no in-grid waits at all).
+        constexpr uint32_t kProbe = 256;
+        uint32_t *d_x = nullptr, h_x[kProbe];
+        HIPB(hipMalloc((void **)&d_x, kProbe * sizeof(uint32_t)));
+        hipLaunchKernelGGL(xcc_probe_kernel, dim3(kProbe), dim3(64), 0, c->stream, d_x);
+        HIPB(hipGetLastError());
+        HIPB(hipMemcpyAsync(h_x, d_x, sizeof h_x, hipMemcpyDeviceToHost, c->stream));
+        HIPB(hipStreamSynchronize(c->stream));
+        (void)hipFree(d_x);
+        uint32_t seen = 0;
+        bool rr = true;
+        for (uint32_t b = 0; b < kProbe; b++) {
+            seen |= 1u << (h_x[b] & 15u);
+            if (h_x[b] != h_x[b % 8u]) rr = false;
+        }
+        c->xcc_count = (uint32_t)__builtin_popcount(seen);
+        for (uint32_t b = 1; b < 8u; b++)
+            for (uint32_t k = 0; k < b; k++)
+                if (h_x[b] == h_x[k]) rr = false;
+        c->xcc_round_robin = rr && c->xcc_count == 8u;
+        if (!c->xcc_round_robin) c->merge_fin = false;
+    }
 #undef HIPB
     *out = c;
     return F2V_OK;
@@ -863,6 +912,7 @@ int f2v_destroy(f2v_handle c) {
                     c->d_partials, c->d_table, c->d_items, c->d_hubs, c->d_ready, c->d_kerr, c->push.flags, c->push.d_err, c->push.d_masks, c->push.d_patch, c->push.landing_buf};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (c->h_kerr) (void)hipHostFree(c->h_kerr);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return F2V_OK;
@@ -1033,6 +1083,11 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
         c->merge_fin = value != 0;
         return F2V_OK;
     }
+    if (!strcmp(name, "tree_timeout_ms")) {
+        if (value < 1 || value > 600000) return fail(F2V_EINVAL, "tree_timeout_ms must be 1..600000");
+        c->tree_timeout_ms = value;
+        return F2V_OK;
+    }
     if (!strcmp(name, "push_landing")) {  // takes effect at the next f2v_push_export
         c->push.force_landing = value != 0;
         return F2V_OK;
@@ -1069,6 +1124,9 @@ int f2v_get_param(f2v_handle c, const char *name, int64_t *out) {
     if (!strcmp(name, "push_timeout_ms")) { *out = c->push.timeout_ms; return F2V_OK; }
     if (!strcmp(name, "push_fused")) { *out = c->push.fused ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "merge_finalize")) { *out = c->merge_fin ? 1 : 0; return F2V_OK; }
+    if (!strcmp(name, "tree_timeout_ms")) { *out = c->tree_timeout_ms; return F2V_OK; }
+    if (!strcmp(name, "xcc_count")) { *out = c->xcc_count; return F2V_OK; }
+    if (!strcmp(name, "xcc_round_robin")) { *out = c->xcc_round_robin ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "push_landing")) { *out = (c->push.attached || c->push.exported) ? (c->push.landing ? 1 : 0) : (c->push.force_landing ? 1 : 0); return F2V_OK; }
     if (!strcmp(name, "push_world")) { *out = c->push.attached ? c->push.world : 0; return F2V_OK; }
     if (!strcmp(name, "push_rank")) { *out = c->push.rank; return F2V_OK; }
@@ -1365,9 +1423,29 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
     HIPC(hipEventCreate(&ev1));
     HIPC(hipEventRecord(ev0, c->stream));
     std::vector<uint32_t> walks;
-    // F2V_PUSH_CHAOS=<seed>: protocol test -- every rank stalls at random minibatches (different ones on every rank)
+#ifdef F2V_TEST_HOOKS
+    // F2V_PUSH_CHAOS=<seed> (self-test build only): every rank stalls at random minibatches (different ones on every rank)
     unsigned long long chaos = 0;
     if (const char *e = getenv("F2V_PUSH_CHAOS")) chaos = (strtoull(e, nullptr, 10) + 1) * 0x9E3779B97F4A7C15ull + c->push.rank * 0xD1B54A32D192ED03ull;
+#endif
+    // The kernels' error words (a combine-tree wait that gave up) are copied to pinned memory at the end of every epoch,
+    // stream-ordered, and looked at without blocking as soon as the copy has run: a lost run fails within an epoch or two
+    // of the give-up instead of at its very end.  Four copies may be in flight (ring of events / 64-byte slots of h_kerr).
+    constexpr int kErrRing = 4;
+    hipEvent_t err_ev[kErrRing];
+    bool err_used[kErrRing] = {};
+    for (auto &e : err_ev) HIPC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    auto free_err_ring = [&] { for (auto &e : err_ev) (void)hipEventDestroy(e); };
+    auto poll_errors = [&](bool wait_slot, int slot) -> const uint32_t * {  // -> the error words if some epoch gave up
+        for (int k = 0; k < kErrRing; k++) {
+            if (!err_used[k]) continue;
+            if (wait_slot && k == slot) (void)hipEventSynchronize(err_ev[k]);
+            else if (hipEventQuery(err_ev[k]) != hipSuccess) continue;
+            err_used[k] = false;
+            if (c->h_kerr[16 * k]) return c->h_kerr + 16 * k;
+        }
+        return nullptr;
+    };
     const bool graphed = c->use_graph && math != 7 && all_upfront && iters >= 2 && !sharded;
     if (graphed) {
         // hipGraph replay: an epoch's launch chain is identical every epoch except for (a) which of the two matrices
@@ -1427,13 +1505,15 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
             const uint32_t hi = (uint32_t)std::min<uint64_t>((uint64_t)lo + batch, n);
             uint32_t my_lo = lo, my_hi = hi;
             if (sharded) shard_of(c, math == 7, lo, hi, c->push.rank, c->push.world, &my_lo, &my_hi);
-            if (exchanging && chaos) {  // test hook: random host-side stalls skew the ranks against each other
+#ifdef F2V_TEST_HOOKS
+            if (exchanging && chaos) {  // random host-side stalls skew the ranks against each other
                 chaos = chaos * 6364136223846793005ull + 1442695040888963407ull;
                 if (((chaos >> 33) & 7u) == 0u) {
                     HIPC(hipStreamSynchronize(c->stream));
                     std::this_thread::sleep_for(std::chrono::microseconds((chaos >> 40) % 3000u));
                 }
             }
+#endif
             if ((rc = launch_step(c, math, lo, hi, my_lo, my_hi, d_epoch_ids + (size_t)b * stride, ns, lr, bs_mode, exchanging && c->push.fused, d_masks)) != F2V_OK) return rc;
             if (exchanging) {
                 if (!c->push.fused && (rc = launch_push(c, c->cur ^ 1, d_masks, lo, my_lo, my_hi)) != F2V_OK) return rc;
@@ -1442,7 +1522,26 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
             }
         }
         if (exchanging) c->push.rows_pushed += need_based ? c->push.pushed_per_epoch : (uint64_t)0;
+        if (c->merge_fin) {
+            const int slot = (int)(it % kErrRing);
+            const uint32_t *bad = poll_errors(err_used[slot], slot);  // the slot about to be reused is waited for (4 epochs old)
+            if (!bad) {
+                HIPC(hipMemcpyAsync(c->h_kerr + 16 * slot, c->d_kerr, 64, hipMemcpyDeviceToHost, c->stream));
+                HIPC(hipEventRecord(err_ev[slot], c->stream));
+                err_used[slot] = true;
+            } else {
+                uint32_t e[16];
+                memcpy(e, bad, sizeof e);
+                free_err_ring();
+                (void)hipEventDestroy(ev0);
+                (void)hipEventDestroy(ev1);
+                char where[96];
+                snprintf(where, sizeof where, "%s (noticed after epoch %u of %u)", sharded ? "f2v_train_sharded" : "f2v_train", it + 1, iters);
+                return kernel_gave_up(c, where, e);
+            }
+        }
     }
+    free_err_ring();
     if (exchanging && !need_based) c->push.rows_pushed = c->push.rows_allgather;
     if ((rc = flush_pending(c)) != F2V_OK) return rc;
     if (need_based && iters > 0) {
@@ -1574,6 +1673,13 @@ int f2v_push_attach(f2v_handle c, uint32_t rank, uint32_t world, const void *all
     return F2V_OK;
 }
 
+#ifdef F2V_TEST_HOOKS
+int f2v_test_withhold_flag(f2v_handle c, uint32_t slot) {
+    if (!c) return fail(F2V_EINVAL, "null handle");
+    c->test_withhold_slot = slot;
+    return F2V_OK;
+}
+
 int f2v_test_push_attach_local(f2v_handle c, uint32_t rank, uint32_t world, const f2v_handle *all) {
     if (!c || !all) return fail(F2V_EINVAL, "f2v_test_push_attach_local: null argument");
     if (world == 0 || world > (uint32_t)kMaxRanks || rank >= world || all[rank] != c) return fail(F2V_EINVAL, "f2v_test_push_attach_local: rank %u of %u", rank, world);
@@ -1594,6 +1700,8 @@ int f2v_test_push_attach_local(f2v_handle c, uint32_t rank, uint32_t world, cons
     c->push.exported = false;
     return F2V_OK;
 }
+
+#endif  // F2V_TEST_HOOKS
 
 int f2v_push_detach(f2v_handle c) {
     if (!c) return fail(F2V_EINVAL, "null handle");
@@ -1644,6 +1752,7 @@ int f2v_push_stats(f2v_handle c, uint64_t *rows_pushed_out, uint64_t *rows_allga
     return F2V_OK;
 }
 
+#ifdef F2V_TEST_HOOKS
 // PMC calibration hook: gathers `rows` distinct rows of 128 floats (a random permutation, so every
 // 512-byte row is fetched exactly once) with the step kernel's access pattern; `reps` launches.
 // Known HBM read volume per launch: rows * 512 bytes (+ 4 bytes per row of ids).
@@ -1672,15 +1781,17 @@ int f2v_test_gather_calibration(int device, uint32_t rows, uint32_t reps) {
     return F2V_OK;
 }
 
+#endif  // F2V_TEST_HOOKS
+
 // Stand-alone rehearsal of what f2v_push_attach + the push kernels need from the machine, meant to run in a
 // THROW-AWAY process before the real engines exist: allocate `bytes` of device memory and a fine-grained flag array
 // on `device`, swap IPC handles with the other ranks through files in `dir`, map theirs, store a word at both ends of
 // every peer's buffer and into every peer's flags from a kernel, and check what the peers stored here.  Whatever goes
 // wrong -- a mapping call that never returns, a fault on the first remote store -- happens to this process.
-int f2v_test_ipc_preflight(int device, uint32_t rank, uint32_t world, const char *dir, uint64_t bytes, double timeout_s) {
-    if (!dir || world == 0 || world > (uint32_t)kMaxRanks || rank >= world || bytes < 4096) return fail(F2V_EINVAL, "f2v_test_ipc_preflight: bad argument");
+int f2v_diag_ipc_preflight(int device, uint32_t rank, uint32_t world, const char *dir, uint64_t bytes, double timeout_s) {
+    if (!dir || world == 0 || world > (uint32_t)kMaxRanks || rank >= world || bytes < 4096) return fail(F2V_EINVAL, "f2v_diag_ipc_preflight: bad argument");
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(F2V_ENODEV, "f2v_test_ipc_preflight: device %d of %d", device, ndev);
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(F2V_ENODEV, "f2v_diag_ipc_preflight: device %d of %d", device, ndev);
     HIPC(hipSetDevice(device));
     uint32_t *data = nullptr;
     unsigned long long *flags = nullptr;
@@ -1715,7 +1826,7 @@ int f2v_test_ipc_preflight(int device, uint32_t rank, uint32_t world, const char
             std::this_thread::sleep_for(std::chrono::milliseconds(2));
         }
     };
-    if (!publish("handles", &mine, sizeof mine)) return fail(F2V_EIO, "f2v_test_ipc_preflight: cannot write into %s", dir);
+    if (!publish("handles", &mine, sizeof mine)) return fail(F2V_EIO, "f2v_diag_ipc_preflight: cannot write into %s", dir);
     PreflightArgs a{};
     a.self = rank;
     a.world = world;
@@ -1723,7 +1834,7 @@ int f2v_test_ipc_preflight(int device, uint32_t rank, uint32_t world, const char
     a.last_word = bytes / 4 - 1;
     for (uint32_t r = 0; r < world; r++) {
         if (r == rank) { a.data[r] = data; a.flags[r] = flags; continue; }
-        if (!await("handles", r, &theirs, sizeof theirs)) return fail(F2V_ESTATE, "f2v_test_ipc_preflight: rank %u never published its handles", r);
+        if (!await("handles", r, &theirs, sizeof theirs)) return fail(F2V_ESTATE, "f2v_diag_ipc_preflight: rank %u never published its handles", r);
         HIPC(hipIpcOpenMemHandle((void **)&a.data[r], theirs.data, hipIpcMemLazyEnablePeerAccess));
         HIPC(hipIpcOpenMemHandle((void **)&a.flags[r], theirs.flags, hipIpcMemLazyEnablePeerAccess));
     }
@@ -1731,9 +1842,9 @@ int f2v_test_ipc_preflight(int device, uint32_t rank, uint32_t world, const char
     HIPC(hipGetLastError());
     HIPC(hipDeviceSynchronize());
     char one = 1;
-    if (!publish("stored", &one, 1)) return fail(F2V_EIO, "f2v_test_ipc_preflight: cannot write into %s", dir);
+    if (!publish("stored", &one, 1)) return fail(F2V_EIO, "f2v_diag_ipc_preflight: cannot write into %s", dir);
     for (uint32_t r = 0; r < world; r++)
-        if (r != rank && !await("stored", r, &one, 1)) return fail(F2V_ESTATE, "f2v_test_ipc_preflight: rank %u never finished its stores", r);
+        if (r != rank && !await("stored", r, &one, 1)) return fail(F2V_ESTATE, "f2v_diag_ipc_preflight: rank %u never finished its stores", r);
     std::vector<uint32_t> head(world), tail(world);
     std::vector<unsigned long long> fl(world);
     HIPC(hipMemcpy(head.data(), data, world * 4, hipMemcpyDeviceToHost));
@@ -1744,20 +1855,20 @@ int f2v_test_ipc_preflight(int device, uint32_t rank, uint32_t world, const char
         const uint32_t want = 0xF2F00000u + r;
         if (head[r] != want || tail[world - 1 - r] != want || fl[r] != want) bad++;
     }
-    if (!publish("checked", &one, 1)) return fail(F2V_EIO, "f2v_test_ipc_preflight: cannot write into %s", dir);
+    if (!publish("checked", &one, 1)) return fail(F2V_EIO, "f2v_diag_ipc_preflight: cannot write into %s", dir);
     for (uint32_t r = 0; r < world; r++)  // nobody unmaps or frees while a peer may still be reading
         if (r != rank && !await("checked", r, &one, 1)) break;
     for (uint32_t r = 0; r < world; r++)
         if (r != rank) { (void)hipIpcCloseMemHandle(a.data[r]); (void)hipIpcCloseMemHandle(a.flags[r]); }
     (void)hipFree(data);
     (void)hipFree(flags);
-    if (bad) return fail(F2V_ENODEV, "f2v_test_ipc_preflight: %d of %u peers' stores did not arrive intact", bad, world);
+    if (bad) return fail(F2V_ENODEV, "f2v_diag_ipc_preflight: %d of %u peers' stores did not arrive intact", bad, world);
     return F2V_OK;
 }
 
 // Streaming-copy ceiling of this card: `reps` copies of `bytes` (read + written = 2*bytes each), best rate in GB/s.
-int f2v_test_stream_copy(int device, uint64_t bytes, uint32_t reps, double *gbps_out) {
-    if (!gbps_out || bytes < 4096 || reps == 0) return fail(F2V_EINVAL, "f2v_test_stream_copy: bad argument");
+int f2v_diag_stream_copy(int device, uint64_t bytes, uint32_t reps, double *gbps_out) {
+    if (!gbps_out || bytes < 4096 || reps == 0) return fail(F2V_EINVAL, "f2v_diag_stream_copy: bad argument");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(F2V_ENODEV, "no such HIP device");
     HIPC(hipSetDevice(device));
@@ -1785,6 +1896,7 @@ int f2v_test_stream_copy(int device, uint64_t bytes, uint32_t reps, double *gbps
     return F2V_OK;
 }
 
+#ifdef F2V_TEST_HOOKS
 int f2v_test_wave_reduce(int device, const float *in, uint32_t rows, uint32_t width, float *out) {
     if (!in || !out || width == 0 || width > 512) return fail(F2V_EINVAL, "f2v_test_wave_reduce: bad argument");
     int ndev = 0;
@@ -1802,5 +1914,6 @@ int f2v_test_wave_reduce(int device, const float *in, uint32_t rows, uint32_t wi
     (void)hipFree(d_out);
     return F2V_OK;
 }
+#endif  // F2V_TEST_HOOKS
 
 }  // extern "C"

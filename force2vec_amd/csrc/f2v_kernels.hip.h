@@ -104,7 +104,11 @@ struct StepArgs {
     uint32_t *ready;
     uint32_t *err;
     unsigned long long timeout_ticks;
+#ifdef F2V_TEST_HOOKS
+    uint32_t test_withhold_slot;      // f2v_test_withhold_flag: the piece with this partial slot never announces (kNoSlot: none)
+#endif
 };
+constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 
 struct FinalizeArgs {
     const float *X;
@@ -548,22 +552,33 @@ __device__ __forceinline__ void finalize_tree_node(const FinalizeTreeArgs &a, ui
     const float *p = f.partials + (size_t)h.in_slot * D;
     float Y[VEC];
     if (w >= a.first_dep) {
+        // Wait for the sums this node adds.  A wait that gives up -- its own time-out, or another node's (err is set: the
+        // launch is lost) -- makes the node return WITHOUT storing or announcing anything: a sum that was never announced is
+        // never added, whoever waits for this node gives up in turn, and the grid drains at once.  The rows such nodes were
+        // to produce keep their old contents; the host sees err at the end of the epoch and fails the call (F2V_ESTATE).
         const unsigned long long t0 = wall_clock64();
-        const bool lost = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;  // an earlier launch gave up: no more waiting
-        for (uint32_t c = lane; c < h.n && !lost; c += 64u) {
-            uint32_t seen;
+        bool gave_up = false;
+        for (uint32_t c = lane; c < h.n && !gave_up; c += 64u) {
+            uint32_t seen, spins = 0;
             while ((seen = __hip_atomic_load(a.ready + h.in_slot + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != a.seq) {
                 __builtin_amdgcn_s_sleep(1);
+                if ((++spins & 15u) != 0u) continue;
+                if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { gave_up = true; break; }
                 if (wall_clock64() - t0 > a.timeout_ticks) {
-                    // err[0] code, [1] how many waits gave up, [2..6] the first of them: node, slot, flag seen, seq, node count
-                    __hip_atomic_store(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // err[0] code, [1] how many waits timed out, [2..7] the first of them: node, slot, flag seen, seq, node count, first dependent
                     if (__hip_atomic_fetch_add(a.err + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
                         a.err[2] = w; a.err[3] = h.in_slot + c; a.err[4] = seen; a.err[5] = a.seq; a.err[6] = f.n_items; a.err[7] = a.first_dep;
                     }
+                    __hip_atomic_store(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    gave_up = true;
                     break;
                 }
             }
         }
+        if (__builtin_amdgcn_ballot_w64(gave_up) != 0ull) return;
+        // every poll of this wave has returned its value before the first load of a sum is issued (and the compiler may
+        // not move those loads up: relaxed atomics of different addresses are otherwise unordered for it)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         add_partials<VEC, EXACT, true>(p, h.n, lane, D, Y);
     } else {
         add_partials<VEC, EXACT, false>(p, h.n, lane, D, Y);
@@ -862,6 +877,9 @@ __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
     if constexpr (PUSH) __builtin_amdgcn_s_waitcnt(0);  // the peers' memory has acknowledged this wave's rows
     if (a.fin_items) {
         __builtin_amdgcn_s_waitcnt(0);  // partial sums are in memory before they are announced
+#ifdef F2V_TEST_HOOKS
+        if ((it.flags & kItemSlotMask) == a.test_withhold_slot) return;  // fault injection: this piece never announces its sum
+#endif
         if (active && partial && t == 0u) __hip_atomic_store(a.ready + (it.flags & kItemSlotMask), a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -1069,6 +1087,7 @@ __global__ void fast_walks_kernel(const uint32_t *rowptr, const uint32_t *colids
     }
 }
 
+#ifdef F2V_TEST_HOOKS
 // PMC calibration: the step kernel's access pattern with a KNOWN byte count.  Every quarter-wave
 // gathers whole 64*NB-float rows (NB x 16 lanes x dwordx4) named by `ids`, each row exactly once,
 // and folds them into a checksum so that the loads stay live.
@@ -1096,7 +1115,9 @@ __global__ __launch_bounds__(256) void gather_calibration_kernel(const float *ta
     if (s == 12345.678f) out[0] = s;  // practically never: keeps the loads from being optimised away
 }
 
-// IPC preflight (f2v_test_ipc_preflight): thread q stores a word into the mapped buffer and the mapped flag array of rank q
+#endif  // F2V_TEST_HOOKS
+
+// IPC preflight (f2v_diag_ipc_preflight): thread q stores a word into the mapped buffer and the mapped flag array of rank q
 struct PreflightArgs {
     uint32_t *data[kMaxRanks];
     unsigned long long *flags[kMaxRanks];
@@ -1117,12 +1138,23 @@ __global__ void preflight_write_kernel(const PreflightArgs a) {
     __hip_atomic_store(f + a.self, (unsigned long long)a.value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Which XCD runs which workgroup?  The one-launch minibatch ties a combine-tree node and the pieces it waits for to
+// workgroups of equal index modulo 8, counting on the dispatcher dealing workgroups round robin over 8 XCDs
+// (MI355X_MICROARCH.md, "Workgroup dispatch": observed, not promised).  f2v_create checks it on the device it got:
+// out[b] = XCC_ID of workgroup b.  Anything else (a partitioned GPU, another XCD count) selects one launch per tree level.
+__global__ void xcc_probe_kernel(uint32_t *out) {
+    uint32_t id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(id));
+    if (threadIdx.x == 0) out[blockIdx.x] = id;
+}
+
 // On-box streaming ceiling: dst = src, 16 bytes per lane, grid-stride
 __global__ __launch_bounds__(256) void stream_copy_kernel(const float4 *src, float4 *dst, uint64_t n4) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n4; k += stride) dst[k] = src[k];
 }
 
+#ifdef F2V_TEST_HOOKS
 // Self-test of the reduction order: out[r] = tree sum of in[r*width .. +width)
 __global__ void wave_reduce_test_kernel(const float *in, uint32_t rows, uint32_t width, float *out) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -1138,6 +1170,7 @@ __global__ void wave_reduce_test_kernel(const float *in, uint32_t rows, uint32_t
     const float s = wave_allreduce_tree(inlane_tree<8>(t));
     if (lane == 0) out[r] = s;
 }
+#endif  // F2V_TEST_HOOKS
 
 }  // namespace f2v
 #endif

@@ -26,8 +26,9 @@ def _f32(a):
 class Engine:
     """One HBM-resident graph + embedding matrix on one MI355X."""
 
-    def __init__(self, rowptr, colids, dim, device=0):
-        self._L = _lib.lib()
+    def __init__(self, rowptr, colids, dim, device=0, selftest=False):
+        # selftest: bind this engine to libf2v_selftest.so (include/f2v_test.h), e.g. for fault injection
+        self._L = _lib.selftest_lib() if selftest else _lib.lib()
         rowptr = np.ascontiguousarray(rowptr, dtype=np.uint32)
         colids = np.ascontiguousarray(colids, dtype=np.uint32)
         self.n = len(rowptr) - 1
@@ -35,8 +36,11 @@ class Engine:
         self.dim = int(dim)
         self.rowptr, self.colids = rowptr, colids
         h = C.c_void_p()
-        check(self._L.f2v_create(_u32(rowptr), _u32(colids), self.n, self.nnz, self.dim, device, C.byref(h)))
+        self._ck(self._L.f2v_create(_u32(rowptr), _u32(colids), self.n, self.nnz, self.dim, device, C.byref(h)))
         self._h = h
+
+    def _ck(self, rc):
+        check(rc, self._L)  # the error text lives in the library that returned the code
 
     def close(self):
         if getattr(self, "_h", None):
@@ -47,152 +51,152 @@ class Engine:
 
     # -- rand() stream / embeddings ---------------------------------------------------------
     def srand(self, seed=1):
-        check(self._L.f2v_srand(self._h, seed))
+        self._ck(self._L.f2v_srand(self._h, seed))
 
     def init_embeddings(self, kind):
-        check(self._L.f2v_init_embeddings(self._h, kind))
+        self._ck(self._L.f2v_init_embeddings(self._h, kind))
 
     def set_embeddings(self, X):
         X = np.ascontiguousarray(X, dtype=np.float32)
         assert X.shape == (self.n, self.dim)
-        check(self._L.f2v_set_embeddings(self._h, _f32(X)))
+        self._ck(self._L.f2v_set_embeddings(self._h, _f32(X)))
 
     def get_embeddings(self):
         X = np.empty((self.n, self.dim), dtype=np.float32)
-        check(self._L.f2v_get_embeddings(self._h, _f32(X)))
+        self._ck(self._L.f2v_get_embeddings(self._h, _f32(X)))
         return X
 
     def rand_index(self, max_num, min_num=0):
         out = C.c_uint32()
-        check(self._L.f2v_rand_index(self._h, max_num, min_num, C.byref(out)))
+        self._ck(self._L.f2v_rand_index(self._h, max_num, min_num, C.byref(out)))
         return out.value
 
     def draw_samples(self, max_num, count, keep=None):
         """`count` randIndex(max_num, 0) draws from the handle's rand() stream; the first `keep` are returned."""
         keep = count if keep is None else keep
         out = np.empty(max(keep, 1), dtype=np.uint32)
-        check(self._L.f2v_rand_indices(self._h, max_num, 0, count, keep, _u32(out)))
+        self._ck(self._L.f2v_rand_indices(self._h, max_num, 0, count, keep, _u32(out)))
         return out[:keep]
 
     def set_param(self, name, value):
-        check(self._L.f2v_set_param(self._h, name.encode(), int(value)))
+        self._ck(self._L.f2v_set_param(self._h, name.encode(), int(value)))
 
     def get_param(self, name):
         v = C.c_int64()
-        check(self._L.f2v_get_param(self._h, name.encode(), C.byref(v)))
+        self._ck(self._L.f2v_get_param(self._h, name.encode(), C.byref(v)))
         return v.value
 
     # -- training -----------------------------------------------------------------------------
     def train(self, option, iters, batch, ns=5, lr=0.02, bs_mode=0):
         """-> device seconds of the epoch loop."""
         sec = C.c_double()
-        check(self._L.f2v_train(self._h, option, iters, batch, ns, lr, bs_mode, C.byref(sec)))
+        self._ck(self._L.f2v_train(self._h, option, iters, batch, ns, lr, bs_mode, C.byref(sec)))
         return sec.value
 
     # -- multi-GPU push exchange over xGMI (include/f2v.h) ----------------------------------------
     def push_export(self):
         """-> bytes: this rank's IPC handles (gather them from all ranks, then push_attach)."""
         buf = C.create_string_buffer(_lib.PUSH_EXPORT_BYTES)
-        check(self._L.f2v_push_export(self._h, buf))
+        self._ck(self._L.f2v_push_export(self._h, buf))
         return buf.raw
 
     def push_attach(self, rank, world, exports):
         blob = b"".join(exports)
         assert len(blob) == world * _lib.PUSH_EXPORT_BYTES
-        check(self._L.f2v_push_attach(self._h, rank, world, C.c_char_p(blob)))
+        self._ck(self._L.f2v_push_attach(self._h, rank, world, C.c_char_p(blob)))
 
     def push_selftest(self):
-        check(self._L.f2v_push_selftest(self._h))
+        self._ck(self._L.f2v_push_selftest(self._h))
 
     def push_detach(self):
-        check(self._L.f2v_push_detach(self._h))
+        self._ck(self._L.f2v_push_detach(self._h))
 
     def push_stats(self):
         a, b = C.c_uint64(), C.c_uint64()
-        check(self._L.f2v_push_stats(self._h, C.byref(a), C.byref(b)))
+        self._ck(self._L.f2v_push_stats(self._h, C.byref(a), C.byref(b)))
         return {"rows_pushed": a.value, "rows_allgather": b.value}
 
     def train_sharded(self, option, iters, batch, ns=5, lr=0.02, bs_mode=0):
         """f2v_train over the attached ranks -> device seconds of the epoch loop (exchange included)."""
         sec = C.c_double()
-        check(self._L.f2v_train_sharded(self._h, option, iters, batch, ns, lr, bs_mode, C.byref(sec)))
+        self._ck(self._L.f2v_train_sharded(self._h, option, iters, batch, ns, lr, bs_mode, C.byref(sec)))
         return sec.value
 
     def minibatch_step(self, option, batch_lo, batch_hi, sample_ids, ns, lr, bs_mode=0, row_lo=None, row_hi=None):
         ids = np.ascontiguousarray(sample_ids, dtype=np.uint32)
-        check(self._L.f2v_minibatch_step(self._h, option, batch_lo, batch_hi,
+        self._ck(self._L.f2v_minibatch_step(self._h, option, batch_lo, batch_hi,
                                          batch_lo if row_lo is None else row_lo, batch_hi if row_hi is None else row_hi,
                                          _u32(ids), len(ids), ns, lr, bs_mode))
 
     def upload_sample_ids(self, ids):
         ids = np.ascontiguousarray(ids, dtype=np.uint32)
-        check(self._L.f2v_upload_sample_ids(self._h, _u32(ids), len(ids)))
+        self._ck(self._L.f2v_upload_sample_ids(self._h, _u32(ids), len(ids)))
 
     def minibatch_step_at(self, option, batch_lo, batch_hi, ids_offset, ns, lr, bs_mode=0, row_lo=None, row_hi=None):
-        check(self._L.f2v_minibatch_step_at(self._h, option, batch_lo, batch_hi,
+        self._ck(self._L.f2v_minibatch_step_at(self._h, option, batch_lo, batch_hi,
                                             batch_lo if row_lo is None else row_lo, batch_hi if row_hi is None else row_hi,
                                             ids_offset, ns, lr, bs_mode))
 
     def flush(self):
-        check(self._L.f2v_flush(self._h))
+        self._ck(self._L.f2v_flush(self._h))
 
     def synchronize(self):
-        check(self._L.f2v_synchronize(self._h))
+        self._ck(self._L.f2v_synchronize(self._h))
 
     def set_walks(self, walks):
         w = np.ascontiguousarray(walks, dtype=np.uint32)
         assert w.size == 5 * self.n
-        check(self._L.f2v_set_walks(self._h, _u32(w)))
+        self._ck(self._L.f2v_set_walks(self._h, _u32(w)))
 
     def generate_walks(self):
         w = np.empty(5 * self.n, dtype=np.uint32)
-        check(self._L.f2v_generate_walks(self._h, _u32(w)))
+        self._ck(self._L.f2v_generate_walks(self._h, _u32(w)))
         return w
 
     def stage_reserve(self, rows):
-        check(self._L.f2v_stage_reserve(self._h, rows))
+        self._ck(self._L.f2v_stage_reserve(self._h, rows))
 
     def stage_read(self, row_lo, row_hi):
         out = np.empty((row_hi - row_lo, self.dim), dtype=np.float32)
-        check(self._L.f2v_stage_read(self._h, row_lo, row_hi, _f32(out)))
+        self._ck(self._L.f2v_stage_read(self._h, row_lo, row_hi, _f32(out)))
         return out
 
     def stage_write(self, row_lo, row_hi, rows):
         rows = np.ascontiguousarray(rows, dtype=np.float32)
         assert rows.shape == (row_hi - row_lo, self.dim)
-        check(self._L.f2v_stage_write(self._h, row_lo, row_hi, _f32(rows)))
+        self._ck(self._L.f2v_stage_write(self._h, row_lo, row_hi, _f32(rows)))
 
     def rows_read(self, ids):
         ids = np.ascontiguousarray(ids, dtype=np.uint32)
         out = np.empty((len(ids), self.dim), dtype=np.float32)
-        check(self._L.f2v_rows_read(self._h, _u32(ids), len(ids), _f32(out)))
+        self._ck(self._L.f2v_rows_read(self._h, _u32(ids), len(ids), _f32(out)))
         return out
 
     def rows_write(self, ids, rows):
         ids = np.ascontiguousarray(ids, dtype=np.uint32)
         rows = np.ascontiguousarray(rows, dtype=np.float32)
         assert rows.shape == (len(ids), self.dim)
-        check(self._L.f2v_rows_write(self._h, _u32(ids), len(ids), _f32(rows)))
+        self._ck(self._L.f2v_rows_write(self._h, _u32(ids), len(ids), _f32(rows)))
 
     def embeddings_device_ptr(self):
         p = C.c_uint64()
-        check(self._L.f2v_embeddings_device_ptr(self._h, C.byref(p)))
+        self._ck(self._L.f2v_embeddings_device_ptr(self._h, C.byref(p)))
         return p.value
 
     def stage_device_ptr(self):
         p = C.c_uint64()
         cap = C.c_uint32()
-        check(self._L.f2v_stage_device_ptr(self._h, C.byref(p), C.byref(cap)))
+        self._ck(self._L.f2v_stage_device_ptr(self._h, C.byref(p), C.byref(cap)))
         return p.value, cap.value
 
     def stream(self):
         s = C.c_uint64()
-        check(self._L.f2v_stream(self._h, C.byref(s)))
+        self._ck(self._L.f2v_stream(self._h, C.byref(s)))
         return s.value
 
     def stats(self):
         s = _lib.Stats()
-        check(self._L.f2v_get_stats(self._h, C.byref(s)))
+        self._ck(self._L.f2v_get_stats(self._h, C.byref(s)))
         return {k: getattr(s, k) for k, _ in s._fields_}
 
 

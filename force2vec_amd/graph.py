@@ -77,6 +77,38 @@ def rmat_edges(scale, edge_factor=16, seed=1, a=0.57, b=0.19, c=0.19):
     return n, (key // n).astype(np.int64), (key % n).astype(np.int64)
 
 
+def rmat_edges_n(n, m, seed=1, a=0.57, b=0.19, c=0.19):
+    """The same generator for a vertex count that is not a power of two: `m` RMAT edges over 2^ceil(log2 n) ids,
+    permuted, folded into [0, n) by `id mod n`, self-loops and duplicate undirected pairs removed."""
+    rng = np.random.default_rng(seed)
+    scale = max(1, int(np.ceil(np.log2(n))))
+    src = np.zeros(m, dtype=np.int64)
+    dst = np.zeros(m, dtype=np.int64)
+    ab, abc = a + b, a + b + c
+    for _ in range(scale):
+        u = rng.random(m)
+        src = (src << 1) | (u >= ab)
+        dst = (dst << 1) | (((u >= a) & (u < ab)) | (u >= abc))
+    del u
+    perm = rng.permutation(1 << scale)
+    src, dst = perm[src] % n, perm[dst] % n
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    key = np.unique(np.maximum(src, dst) * n + np.minimum(src, dst))
+    return n, key // n, key % n
+
+
+# com-Orkut (SURVEY section 8, C4): 3 072 441 vertices, 117 185 083 undirected edges.  The file is not in the container
+# (no network), so BASELINE configs[3] runs on a synthetic power-law graph of that size: ORKUT_M generated edges leave
+# 117.2 M distinct ones (nnz = 234.4 M directed CSR nonzeros).
+ORKUT_N, ORKUT_M = 3072441, 125300000
+
+
+def orkut_like_csr(seed=1):
+    n, s, d = rmat_edges_n(ORKUT_N, ORKUT_M, seed)
+    return csr_from_undirected_edges(n, s, d)
+
+
 def rmat_csr(scale, edge_factor=16, seed=1):
     n, s, d = rmat_edges(scale, edge_factor, seed)
     return csr_from_undirected_edges(n, s, d)

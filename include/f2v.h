@@ -61,7 +61,10 @@ int f2v_get_embeddings(f2v_handle h, float *x_out);
  * the chunk is part of the summation order, so pin it where bits must not depend on the number of GPUs);
  * "hub_fanin": fan-in of the tree that adds a split row's partial sums (0 = one sequential pass);
  * "merge_finalize" (default 1): the trees' nodes run in the step kernel's own grid (one launch per
- * minibatch), 0 = one launch per tree level; "quarter_wave": 0 selects the one-item-per-wavefront
+ * minibatch; every in-grid wait is bounded by "tree_timeout_ms", default 5000 -- a wait that gives up makes the
+ * running f2v_train fail with F2V_ESTATE within an epoch or two, no unannounced sum is ever added, and the handle
+ * falls back to 0), 0 = one launch per tree level; f2v_create selects 0 by itself when its dispatch probe does not
+ * find 8 XCDs taking workgroups round robin ("xcc_count", "xcc_round_robin" answer what it saw); "quarter_wave": 0 selects the one-item-per-wavefront
  * kernel for every D; "waves_per_block"; "rows_in_flight" (4|8); "use_graph" = 1 makes f2v_train replay a
  * captured hipGraph per epoch instead of launching eagerly (same results; measured no faster).
  * Sharded runs: "push_fused" (default 1: the step kernels push their rows themselves, 0: a kernel behind
@@ -157,8 +160,7 @@ int f2v_synchronize(f2v_handle h);
  * engines exchange through a mapped landing buffer of one minibatch (two halves of at most 512 MiB) that a
  * small kernel unpacks behind the barrier -- automatically, or for any size with "push_landing" = 1 (set
  * before f2v_push_export, on every rank alike).  A minibatch must then fit one half.
- * Environment, for tests: F2V_PUSH_CHAOS=<seed> makes every rank stall (drain its stream and sleep up to 3 ms) at
- * random minibatches of f2v_train_sharded; F2V_TREE_TIMEOUT_MS bounds the waits of the combine-tree nodes (5000). */
+ * (Fault injection for the protocol tests lives in the self-test build only: include/f2v_test.h.) */
 #define F2V_PUSH_MAX_RANKS 8
 #define F2V_PUSH_EXPORT_BYTES 256
 int f2v_push_export(f2v_handle h, void *handles_out);
@@ -231,21 +233,13 @@ int f2v_rng_fill(f2v_rng *g, float *out, uint64_t count, int kind);
 /* The 2048-entry sigmoid table of init_SM_TABLE (sample/algorithms.cpp:757-764) as the source defines it. */
 int f2v_sm_table(float *table_out /* 2048 */);
 
-/* ---- self-test hooks (used by tests/ only) ---------------------------------------------- */
-/* Runs the wavefront tree reduction on `rows` rows of `width` (<=512) floats; out[r] = sum. */
-int f2v_test_wave_reduce(int device, const float *in, uint32_t rows, uint32_t width, float *out);
-/* The push exchange between engines of ONE process on one device (direct pointers instead of HIP IPC; every
- * engine is driven by its own host thread): runs the push kernels, masks and flag barriers under a profiler. */
-int f2v_test_push_attach_local(f2v_handle h, uint32_t rank, uint32_t world, const f2v_handle *all);
+/* ---- diagnostics (bench.py, tools/ipc_preflight.py, bin/Force2Vec -gpus) ------------------ */
 /* Rehearsal of the push exchange's needs (IPC mapping of `bytes` of device memory and of fine-grained flags between
  * `world` processes that meet through files in `dir`, remote stores from a kernel), for a throw-away process to run
  * before the real engines exist: a mapping call that never returns or a faulting remote store then costs only it. */
-int f2v_test_ipc_preflight(int device, uint32_t rank, uint32_t world, const char *dir, uint64_t bytes, double timeout_s);
-/* On-box streaming-copy ceiling (read + written bytes per second of a 16-byte-per-lane copy kernel, best of `reps`). */
-int f2v_test_stream_copy(int device, uint64_t bytes, uint32_t reps, double *gbps_out);
-/* PMC calibration: `reps` launches that each gather `rows` distinct 512-byte rows exactly once with
- * the step kernel's access pattern (known HBM read volume rows*516 bytes per launch). */
-int f2v_test_gather_calibration(int device, uint32_t rows, uint32_t reps);
+int f2v_diag_ipc_preflight(int device, uint32_t rank, uint32_t world, const char *dir, uint64_t bytes, double timeout_s);
+/* On-box streaming-copy ceiling: read + written bytes per second (GB/s) of a 16-byte-per-lane copy of `bytes`, best of `reps`. */
+int f2v_diag_stream_copy(int device, uint64_t bytes, uint32_t reps, double *gbps_out);
 
 #ifdef __cplusplus
 }

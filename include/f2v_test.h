@@ -1,0 +1,32 @@
+/*
+ * f2v_test.h -- self-test hooks of libf2v.  NOT part of the product library: they exist only in
+ * force2vec_amd/libf2v_selftest.so, the same sources built with -DF2V_TEST_HOOKS (Makefile), which tests/ and a few
+ * tools/ load instead of libf2v.so where they need fault injection or a look inside.  That build also understands
+ * the environment variable F2V_PUSH_CHAOS=<seed>: every rank of f2v_train_sharded drains its stream and sleeps up to
+ * 3 ms at random minibatches (other ones on every rank) -- the protocol test under rank skew.
+ */
+#ifndef F2V_TEST_H_
+#define F2V_TEST_H_
+
+#include "f2v.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Runs the wavefront tree reduction on `rows` rows of `width` (<=512) floats; out[r] = sum. */
+int f2v_test_wave_reduce(int device, const float *in, uint32_t rows, uint32_t width, float *out);
+/* The push exchange between engines of ONE process on one device (direct pointers instead of HIP IPC; every
+ * engine is driven by its own host thread): runs the push kernels, masks and flag barriers under a profiler. */
+int f2v_test_push_attach_local(f2v_handle h, uint32_t rank, uint32_t world, const f2v_handle *all);
+/* PMC calibration: `reps` launches that each gather `rows` distinct 512-byte rows exactly once with
+ * the step kernel's access pattern (known HBM read volume rows*516 bytes per launch). */
+int f2v_test_gather_calibration(int device, uint32_t rows, uint32_t reps);
+/* Fault injection for the one-launch minibatch: the hub piece that owns partial-sum slot `slot` never announces its
+ * sum (0xFFFFFFFF: none), so the combine-tree node that adds it has to give up its wait ("tree_timeout_ms"). */
+int f2v_test_withhold_flag(f2v_handle h, uint32_t slot);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* F2V_TEST_H_ */

@@ -16,7 +16,7 @@ def pytest_configure(config):
     # a fresh checkout has no built artefacts: build the product library / CLI and the test oracle once
     # (hipcc cross-compiles without a GPU; on the GPU box the prebuilt files travel with the snapshot)
     import subprocess
-    if not (os.path.exists(os.path.join(ROOT, "force2vec_amd", "libf2v.so")) and os.path.exists(os.path.join(ROOT, "bin", "Force2Vec"))):
+    if not all(os.path.exists(os.path.join(ROOT, p)) for p in ("force2vec_amd/libf2v.so", "force2vec_amd/libf2v_selftest.so", "bin/Force2Vec")):
         subprocess.check_call(["make", "-s", "-C", ROOT, "all"])
     if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])

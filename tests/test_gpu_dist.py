@@ -215,10 +215,13 @@ def test_push_exchange_with_skewed_ranks(mode, tmp_path, monkeypatch):
     rank), so ranks run ahead of and behind each other by whole minibatches: the barrier, the two landing-buffer halves
     and the epoch's matrix swap must keep every replica bit-identical all the same."""
     import torch.multiprocessing as mp
+    from force2vec_amd import _lib
+    monkeypatch.setenv("F2V_LIBRARY", _lib.SELFTEST_LIB_PATH)  # the spawned ranks load the self-test build: fault injection lives there
     monkeypatch.setenv("F2V_PUSH_CHAOS", "7")
     case = ("pubmed.mtx", 5, 4, 1024, 64, 0)
     mp.spawn(_gloo_worker, args=(3, _free_port(), case, str(tmp_path), mode), nprocs=3, join=True)
     monkeypatch.delenv("F2V_PUSH_CHAOS")
+    monkeypatch.delenv("F2V_LIBRARY")
     want = _single_twice(case)
     for r in range(3):
         assert np.array_equal(np.load(str(tmp_path / ("r%d.npy" % r))), want)

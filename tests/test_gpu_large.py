@@ -1,0 +1,147 @@
+"""-m gpu: BASELINE configs[3] and configs[4] at FULL size on one MI355X, and the push exchange at the matrix size
+that forces its landing-buffer path.
+
+  configs[4]  synthetic RMAT scale-24 (16.8 M vertices, ~521 M directed nonzeros, N*D = 2^31: 64-bit row offsets,
+              2 x 8 GiB of embeddings), option 11 (load-balanced t-distribution), D = 128
+  configs[3]  com-Orkut-sized power-law graph (3 072 441 vertices, ~234 M nonzeros; the real file is not in the
+              container: force2vec_amd.graph.orkut_like_csr), option 6 (sigmoid), D = 128
+
+The oracle cannot run an epoch at these sizes in seconds, so parity is checked through size-independent properties:
+two engines give identical bits (determinism under load), and ONE more minibatch is compared, on sampled rows that
+include the batch's largest hubs and zero-degree rows, with the oracle's row function applied to the downloaded
+pre-step matrix (bit for bit, ORDER_TREE with the engine's hub chunk); rows outside the minibatch must not change."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def cached_graph(name, build):
+    """CSR under /tmp (generation is setup; a second test or a child process reads the cache)."""
+    path = "/tmp/f2v_test_%s.npz" % name
+    if os.path.exists(path):
+        try:
+            z = np.load(path)
+            return z["rowptr"], z["colids"]
+        except Exception:
+            pass
+    rowptr, colids = build()
+    tmp = path + ".%d.tmp.npz" % os.getpid()
+    np.savez(tmp, rowptr=rowptr, colids=colids)
+    os.replace(tmp, path)
+    return rowptr, colids
+
+
+def full_size_check(F, rowptr, colids, option, batch, n_sample=32):
+    n, dim = len(rowptr) - 1, 128
+    math = {5: 5, 8: 5, 11: 5, 6: 6, 9: 6}[option]
+    deg = np.diff(rowptr.astype(np.int64))
+    engs = []
+    for _ in range(2):
+        e = F.Engine(rowptr, colids, dim)
+        e.srand(1)
+        e.init_embeddings(0 if math == 5 else 1)
+        e.train(option, 1, batch)
+        engs.append(e)
+    before = engs[0].get_embeddings()
+    other = engs[1].get_embeddings()
+    engs[1].close()
+    assert np.array_equal(before, other)
+    del other
+    assert np.isfinite(before[:: max(1, n // 4096)]).all()
+    eng = engs[0]
+    st = eng.stats()
+    assert st["nnz"] == len(colids) and st["rows"] == n and st["hub_rows"] > 0
+    chunk = eng.get_param("hub_chunk")
+    rng = np.random.default_rng(9)
+    lo = (n // 2 // batch) * batch
+    hi = min(lo + batch, n)
+    ids = rng.integers(0, n - 1, 5).astype(np.uint32)
+    ids[0] = lo + int(np.argmax(deg[lo:hi]))  # the batch's largest hub samples itself: NaN -> -5 rule (option 5 maths)
+    eng.minibatch_step(option, lo, hi, ids, 5, 0.02)
+    after = eng.get_embeddings()
+    zero_rows = lo + np.flatnonzero(deg[lo:hi] == 0)[:6]
+    rows = np.concatenate([rng.integers(lo, hi, n_sample), lo + np.argsort(deg[lo:hi])[-6:], zero_rows])
+    assert deg[rows].max() > 8 * chunk and len(zero_rows) == 6 and len(rows) >= 32
+    for i in rows:
+        want = O.row(math, rowptr, colids, before, int(i), ids, 0.02, order=O.ORDER_TREE, chunk=chunk)
+        assert np.array_equal(after[i], want), (int(i), int(deg[i]), float(np.abs(after[i] - want).max()))
+    assert np.array_equal(after[:lo], before[:lo]) and np.array_equal(after[hi:], before[hi:])
+    eng.close()
+    return len(rows)
+
+
+def test_config5_rmat24_option11_full_size():
+    """BASELINE configs[4]: RMAT scale-24, option 11, D = 128, batch 262144 (64 minibatches per epoch)."""
+    import force2vec_amd as F
+    from force2vec_amd.graph import rmat_csr
+    rowptr, colids = cached_graph("rmat24", lambda: rmat_csr(24, 16, seed=1))
+    assert len(rowptr) - 1 == 1 << 24 and len(colids) > 500_000_000
+    assert full_size_check(F, rowptr, colids, 11, 262144) >= 32
+
+
+def test_config4_orkut_sized_option6_full_size():
+    """BASELINE configs[3]: com-Orkut's size (3 072 441 vertices, 117.1 M undirected edges), option 6, D = 128."""
+    import force2vec_amd as F
+    from force2vec_amd.graph import ORKUT_N, orkut_like_csr
+    rowptr, colids = cached_graph("orkut_like", orkut_like_csr)
+    assert len(rowptr) - 1 == ORKUT_N and abs(len(colids) / 2 - 117_185_083) < 0.01 * 117_185_083
+    assert full_size_check(F, rowptr, colids, 6, 131072) >= 32
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _landing_worker(rank, world, port, outdir):
+    import torch.distributed as dist
+    import force2vec_amd as F
+    from force2vec_amd import dist as fdist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    z = np.load("/tmp/f2v_test_rmat22e8.npz")
+    eng = F.Engine(z["rowptr"], z["colids"], 128, device=0)
+    eng.set_param("hub_chunk", 64)
+    eng.srand(1)
+    eng.init_embeddings(0)
+    eng.set_param("push_timeout_ms", 20000)
+    comm = fdist.PushExchange(dist, rank, world)
+    fdist.ShardedTrainer(eng, rank, world, comm).train(5, 1, 262144, 5, 0.02, 0)
+    assert eng.get_param("push_landing") == 1  # chosen by the engine itself: the matrices are over 2 GiB
+    X = eng.get_embeddings()
+    # a digest per rank instead of 2 GiB files: row sums in float64 and a strided sample of raw rows
+    np.savez(os.path.join(outdir, "r%d.npz" % rank), sums=X.sum(axis=1, dtype=np.float64), sample=X[::997].copy())
+    eng.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_push_exchange_lands_at_2gib(tmp_path):
+    """Matrices of 2 GiB and more cannot be mapped through HIP IPC: two ranks (sharing the card) on RMAT scale-22
+    (4.19 M vertices x 128 floats = 2.15 GB per matrix) exchange through the landing buffer WITHOUT being told to, and
+    both replicas equal the single-GPU run."""
+    import torch.multiprocessing as mp
+    import force2vec_amd as F
+    from force2vec_amd.graph import rmat_csr
+    rowptr, colids = cached_graph("rmat22e8", lambda: rmat_csr(22, 8, seed=1))
+    assert (len(rowptr) - 1 + 4096) * 128 * 4 >= 1 << 31
+    mp.spawn(_landing_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    eng = F.Engine(rowptr, colids, 128)
+    eng.set_param("hub_chunk", 64)
+    eng.srand(1)
+    eng.init_embeddings(0)
+    eng.train(5, 1, 262144)
+    X = eng.get_embeddings()
+    eng.close()
+    sums, sample = X.sum(axis=1, dtype=np.float64), X[::997]
+    for r in range(2):
+        z = np.load(str(tmp_path / ("r%d.npz" % r)))
+        assert np.array_equal(z["sums"], sums) and np.array_equal(z["sample"], sample)

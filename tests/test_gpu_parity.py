@@ -43,7 +43,8 @@ def test_wave_reduce_order(F, width):
     rng = np.random.default_rng(width)
     x = (rng.standard_normal((37, width)) * 10 ** rng.uniform(-3, 3, (37, 1))).astype(np.float32)
     out = np.empty(37, dtype=np.float32)
-    _lib.check(_lib.lib().f2v_test_wave_reduce(0, x.ctypes.data_as(_lib.f32p), 37, width, out.ctypes.data_as(_lib.f32p)))
+    T = _lib.selftest_lib()
+    _lib.check(T.f2v_test_wave_reduce(0, x.ctypes.data_as(_lib.f32p), 37, width, out.ctypes.data_as(_lib.f32p)), T)
     assert np.array_equal(out, tree_sum_model(x))
 
 
@@ -157,6 +158,58 @@ def test_single_launch_combine_tree_under_load(F, dim, fanin):
         res.append(eng.get_embeddings())
         eng.close()
     assert np.array_equal(res[0], res[1]) and np.isfinite(res[0]).all()
+
+
+def test_combine_tree_give_up_is_safe_reported_at_once_and_recoverable(F):
+    """The one-launch minibatch makes tree nodes WAIT for partial sums inside the grid.  Fault injection (self-test
+    build: one hub piece never announces its sum) with a 1-ms bound: the node gives up, nothing unannounced is ever
+    added, f2v_train fails with F2V_ESTATE within a few epochs of a 300-epoch run (not at its end), and the handle is
+    usable afterwards -- it has switched itself to one launch per tree level, and switching back works too."""
+    import re
+    from force2vec_amd import _lib
+    T = _lib.selftest_lib()
+    n, dim, batch = 600, 128, 200
+    rowptr, colids = random_graph(n, 6, seed=5, hubs=((3, 400), (500, 200)))
+    rng = np.random.default_rng(4)
+    X0 = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    eng = F.Engine(rowptr, colids, dim, selftest=True)
+    if not eng.get_param("xcc_round_robin"):
+        eng.close()
+        pytest.skip("the dispatch probe did not find 8 XCDs taking workgroups round robin: merge_finalize is off on this device")
+    assert eng.get_param("xcc_count") == 8 and eng.get_param("merge_finalize") == 1
+    eng.set_param("hub_chunk", 8)
+    eng.set_param("hub_fanin", 4)
+    O.set_fanin(4)
+    try:
+        want = O.train(5, rowptr, colids, dim, 3, batch, order=O.ORDER_TREE, chunk=8, X0=X0)
+        eng.set_embeddings(X0)
+        eng.srand(1)
+        eng.train(5, 3, batch)
+        assert np.array_equal(eng.get_embeddings(), want)          # healthy: one launch per minibatch
+        eng.set_param("tree_timeout_ms", 1)
+        _lib.check(T.f2v_test_withhold_flag(eng._h, 0), T)         # slot 0: first piece of the first hub row of a launch
+        eng.set_embeddings(X0)
+        eng.srand(1)
+        with pytest.raises(F.F2VError) as ex:
+            eng.train(5, 300, batch)
+        msg = str(ex.value)
+        assert ex.value.code == _lib.F2V_ESTATE and "combine-tree waits gave up" in msg and "merge_finalize" in msg
+        noticed = int(re.search(r"noticed after epoch (\d+) of 300", msg).group(1))
+        assert noticed <= 16, msg                                   # at once, not at the end of the run
+        with pytest.raises(F.F2VError):                             # the embeddings are invalid until they are set again
+            eng.get_embeddings()
+        _lib.check(T.f2v_test_withhold_flag(eng._h, 0xFFFFFFFF), T)
+        assert eng.get_param("merge_finalize") == 0                 # fell back by itself
+        for merge in (0, 1):
+            eng.set_param("merge_finalize", merge)
+            eng.set_param("tree_timeout_ms", 5000)
+            eng.set_embeddings(X0)
+            eng.srand(1)
+            eng.train(5, 3, batch)
+            assert np.array_equal(eng.get_embeddings(), want)
+    finally:
+        O.set_fanin(32)
+        eng.close()
 
 
 def _csr(n, edges):
@@ -570,10 +623,10 @@ def test_self_test_hooks_run(F, tmp_path):
     """The measurement / rehearsal hooks bench.py relies on: streaming-copy ceiling, single-rank IPC preflight."""
     import ctypes
     g = ctypes.c_double()
-    F._lib.check(F._lib.lib().f2v_test_stream_copy(0, 64 << 20, 2, ctypes.byref(g)))
+    F._lib.check(F._lib.lib().f2v_diag_stream_copy(0, 64 << 20, 2, ctypes.byref(g)))
     assert 100.0 < g.value < 20000.0  # GB/s, read + written
-    F._lib.check(F._lib.lib().f2v_test_ipc_preflight(0, 0, 1, str(tmp_path).encode(), 1 << 20, 5.0))
-    assert F._lib.lib().f2v_test_ipc_preflight(0, 1, 1, str(tmp_path).encode(), 1 << 20, 5.0) != 0  # rank outside the world
+    F._lib.check(F._lib.lib().f2v_diag_ipc_preflight(0, 0, 1, str(tmp_path).encode(), 1 << 20, 5.0))
+    assert F._lib.lib().f2v_diag_ipc_preflight(0, 1, 1, str(tmp_path).encode(), 1 << 20, 5.0) != 0  # rank outside the world
 
 
 def test_two_ranks_ipc_preflight_children(tmp_path):

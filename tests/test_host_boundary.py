@@ -17,16 +17,28 @@ import force2vec_amd as F
 from force2vec_amd import _lib
 
 
-def test_abi_exports_every_declared_symbol():
-    hdr = open(os.path.join(ROOT, "include", "f2v.h")).read()
+def _declared(header):
+    hdr = open(os.path.join(ROOT, "include", header)).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(f2v_[a-z_0-9]+)\s*\(", hdr))
+    return set(re.findall(r"\b(f2v_[a-z_0-9]+)\s*\(", hdr))
+
+
+def test_abi_exports_every_declared_symbol():
+    declared = _declared("f2v.h")
     assert len(declared) >= 30
     L = C.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     assert b"gfx950" in _lib.lib().f2v_version()
+    # the self-test hooks of include/f2v_test.h exist in the self-test build only, never in the product library
+    hooks = _declared("f2v_test.h")
+    assert hooks == set(_lib.TEST_SIGNATURES) and len(hooks) >= 4
+    T = C.CDLL(_lib.SELFTEST_LIB_PATH)
+    for name in hooks:
+        assert hasattr(T, name) and not hasattr(L, name), name
+    for name in declared:
+        assert hasattr(T, name), name
 
 
 def test_no_cpu_fallback():

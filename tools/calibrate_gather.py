@@ -9,5 +9,5 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from force2vec_amd import _lib
 
 ROWS = 4 * 1024 * 1024
-_lib.check(_lib.lib().f2v_test_gather_calibration(0, ROWS, 3))
+_lib.check(_lib.selftest_lib().f2v_test_gather_calibration(0, ROWS, 3), _lib.selftest_lib())
 print("calibration: %d rows x 512 B = %d bytes per launch (+%d bytes of ids)" % (ROWS, ROWS * 512, ROWS * 4))

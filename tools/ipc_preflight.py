@@ -14,7 +14,7 @@ from force2vec_amd import _lib  # ctypes only
 device, rank, world = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 d, nbytes, timeout_s = sys.argv[4], int(sys.argv[5]), float(sys.argv[6])
 os.makedirs(d, exist_ok=True)
-rc = _lib.lib().f2v_test_ipc_preflight(device, rank, world, d.encode(), nbytes, timeout_s)
+rc = _lib.lib().f2v_diag_ipc_preflight(device, rank, world, d.encode(), nbytes, timeout_s)
 if rc != 0:
     print("ipc_preflight[rank %d]: %s" % (rank, _lib.lib().f2v_last_error().decode(errors="replace")), file=sys.stderr, flush=True)
 sys.exit(0 if rc == 0 else 1)

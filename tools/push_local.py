@@ -31,12 +31,12 @@ ref.train(5, 2, batch)
 single = ref.train(5, epochs, batch) / epochs
 want = ref.get_embeddings()
 ref.close()
-engs = [F.Engine(rowptr, colids, 128) for _ in range(world)]
+engs = [F.Engine(rowptr, colids, 128, selftest=True) for _ in range(world)]  # libf2v_selftest.so: the local attach hook
 for e in engs:
     e.srand(1); e.init_embeddings(0); e.push_export(); e.set_param("push_timeout_ms", 3000)
 arr = (C.c_void_p * world)(*[e._h for e in engs])
 for r, e in enumerate(engs):
-    _lib.check(_lib.lib().f2v_test_push_attach_local(e._h, r, world, arr))
+    _lib.check(_lib.selftest_lib().f2v_test_push_attach_local(e._h, r, world, arr), _lib.selftest_lib())
 res = [None] * world
 
 
