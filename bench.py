@@ -14,9 +14,18 @@ barrier; torch.distributed only carries the IPC handles); if it cannot be set up
 run falls back to an RCCL all-gather per minibatch and says so.  After the timed region every rank
 checks its replica bit for bit against a single-GPU run of the same epochs.
 
-Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` (HBM bound,
-algorithmic bytes / launch over the live HIP-event launch time) and `cpu_baseline` (the genuine
-reference binary oracle/_ref timed on this box's host cores on a bounded sample).
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` and `cpu_baseline` (the genuine
+reference binary oracle/_ref timed on this box's host cores on a bounded sample of the same workload).
+
+roofline, bound "hbm": `achieved` = COMPULSORY bytes per launch of the dominant kernel (distinct embedding rows read +
+rows written + neighbour ids + work items: what must cross HBM even if every re-read inside the launch hit a cache,
+counted on the host by the engine) / that kernel's average launch time (HIP events on the engine's stream around the
+epoch loop); `frac` = achieved / 8 TB/s and cannot exceed 1.  The SURVEY 8d figure (every neighbour row charged to HBM,
+"no credit for cache reuse") is kept as `algorithmic_GBs`: it is NOT a fraction of anything -- on a power-law graph hub
+rows are cache hits and it passes the HBM peak.  `traffic` = bytes that left the XCDs' L2s per launch (PMC passes of
+tools/profile_traffic.sh, committed under profiles/): HBM + Infinity Cache together; rocprofv3 exposes no counter on
+the memory side of the Infinity Cache on this part, so HBM bytes lie between `compulsory` ... `traffic`.
+After the timed region (N = 1) one more minibatch is checked on sampled rows against the CPU oracle (`config.verified_rows`).
 """
 import argparse
 import json
@@ -71,56 +80,110 @@ def load_graph(scale, edge_factor, seed):
     return rowptr, colids
 
 
+def write_mtx_fast(path, n, src, dst):
+    """`pattern symmetric` MatrixMarket file of a 10^7-edge list in seconds (pyarrow's CSV writer; np.savetxt takes a minute)."""
+    try:
+        import pyarrow as pa
+        import pyarrow.csv as pacsv
+        with open(path, "wb") as f:
+            f.write(b"%%MatrixMarket matrix coordinate pattern symmetric\n")
+            f.write(b"%d %d %d\n" % (n, n, len(src)))
+            tbl = pa.table({"r": pa.array(src + 1), "c": pa.array(dst + 1)})
+            pacsv.write_csv(tbl, f, pacsv.WriteOptions(include_header=False, delimiter=" "))
+    except ImportError:
+        from force2vec_amd.graph import write_mtx_symmetric
+        write_mtx_symmetric(path, n, src, dst)
+
+
 def cpu_baseline(args):
-    """The reference on this box's host cores, on a bounded sample of the same workload: a smaller RMAT
-    graph (scale args.cpu_scale), same D / ns / lr / batch.  T(iters=k) - T(iters=0) strips the reference's
-    in-timer initialisation.  kind 'reference' = oracle/_ref (the genuine reference, built from
-    /root/reference by oracle/build_ref.sh); fallback kind 'port' = the single-thread C oracle."""
-    from force2vec_amd.graph import edges_from_csr, write_mtx_symmetric
+    """The reference on this box's host cores, on a bounded sample of the same workload: the north-star's 10 M-edge
+    power-law graph (RMAT scale args.cpu_scale = 20 by default: the benchmark's own graph, 15.7 M undirected edges), same
+    D / ns / lr / batch, a few epochs.  T(iters=k) - T(iters=0) strips the reference's in-timer initialisation and leaves
+    its file parsing out.  kind 'reference' = oracle/_ref (the genuine reference, built from /root/reference by
+    oracle/build_ref.sh); fallback kind 'port' = the single-thread C oracle.  The thread count is picked by a short scan on
+    a small graph (RMAT scale-17), the reported number is measured on the large one."""
+    from force2vec_amd.graph import edges_from_csr
     from oracle import oracle as O
-    rowptr, colids = load_graph(args.cpu_scale, 16, 1)
-    n, nnz = len(rowptr) - 1, len(colids)
     cores = os.cpu_count() or 1
     flags = open("/proc/cpuinfo").read()
     avx512 = (" avx512f" in flags) and (" avx512dq" in flags) and O.ref_binary(True) is not None
     exe_ok = O.ref_binary(avx512) is not None
-    sample = "RMAT scale-%d (n=%d, nnz=%d), D=%d ns=5 lr=0.02 batch=%d" % (args.cpu_scale, n, nnz, args.dim, args.batch)
+    rowptr, colids = load_graph(args.cpu_scale, 16, 1)
+    n, nnz = len(rowptr) - 1, len(colids)
+    sample = "RMAT scale-%d (n=%d, nnz=%d = %.1f M undirected edges), D=%d ns=5 lr=0.02 batch=%d" % (args.cpu_scale, n, nnz, nnz / 2e6, args.dim, args.batch)
     if exe_ok:
         option = 11 if avx512 else 5
         with tempfile.TemporaryDirectory() as td:
-            mtx = os.path.join(td, "sample.mtx")
-            src, dst = edges_from_csr(rowptr, colids)
-            write_mtx_symmetric(mtx, n, src, dst)
-
-            def run(iters, threads):
+            def run(mtx, iters, threads):
                 out = run_ref(O, mtx, td, option, iters, args, threads, avx512)
                 for line in out.splitlines():
                     if "Wall time required" in line:
                         return float(line.split(":")[-1].split()[0])
                 raise RuntimeError("reference output not understood:\n" + out)
 
-            # the reference does not scale to every core count on every box: a short scan picks the
-            # thread count that serves it best, the long run below is what is reported
+            # the reference does not scale to every core count on every box: a short scan on a small graph picks the
+            # thread count that serves it best
+            small = os.path.join(td, "small.mtx")
+            rp_s, ci_s = load_graph(min(17, args.cpu_scale), 16, 1)
+            src, dst = edges_from_csr(rp_s, ci_s)
+            write_mtx_fast(small, len(rp_s) - 1, src, dst)
             cands = sorted({c for c in (16, 32, 48, 64, 128, cores) if c <= cores})
             best, best_rate = cores, 0.0
-            t0 = run(0, 1)  # the in-timer initialisation is serial (N*D rand() calls): measured once
+            t0s = run(small, 0, 1)  # the in-timer initialisation is serial (N*D rand() calls): measured once
             for th in cands:
-                rate = 3.0 / max(run(3, th) - t0, 1e-6)
+                rate = 3.0 / max(run(small, 3, th) - t0s, 1e-6)
                 if rate > best_rate:
                     best, best_rate = th, rate
             threads = best
-            k = int(min(2000, max(args.cpu_iters, 12.0 * best_rate)))  # about 12 s of CPU work
-            tk = run(k, threads)
+            mtx = os.path.join(td, "sample.mtx")
+            src, dst = edges_from_csr(rowptr, colids)
+            write_mtx_fast(mtx, n, src, dst)
+            del src, dst
+            t0 = run(mtx, 0, 1)
+            k = max(2, args.cpu_iters)
+            tk = run(mtx, k, threads)
         val = nnz * k / max(tk - t0, 1e-9)
         return {"value": val, "unit": "edges/s", "cores": threads, "kind": "reference",
-                "sample": "%s; oracle/_ref option %d%s, %d epochs in %.2fs, -threads %d (best of %s on a %d-core host)"
+                "sample": "%s; oracle/_ref option %d%s, %d epochs in %.2fs, -threads %d (best of %s in a scan on RMAT scale-17; %d-core host)"
                           % (sample, option, " (AVX512 build)" if avx512 else " (scalar build)", k, tk - t0, threads, cands, cores)}
-    # port: single-thread oracle, a few epochs
+    # port: single-thread oracle, one epoch of the small graph
+    rowptr, colids = load_graph(min(17, args.cpu_scale), 16, 1)
+    n, nnz = len(rowptr) - 1, len(colids)
     X = O.Rng(1).init_embeddings(n, args.dim, 0)
     t0 = time.time()
     O.train(5, rowptr, colids, args.dim, 1, args.batch, X0=X)
     dt = time.time() - t0
-    return {"value": nnz / dt, "unit": "edges/s", "cores": 1, "kind": "port", "sample": sample + "; oracle/f2v_oracle.c, 1 epoch in %.2fs" % dt}
+    return {"value": nnz / dt, "unit": "edges/s", "cores": 1, "kind": "port",
+            "sample": "RMAT scale-17 (n=%d, nnz=%d), D=%d; oracle/f2v_oracle.c (single thread), 1 epoch in %.2fs" % (n, nnz, args.dim, dt)}
+
+
+def verify_rows(F, eng, rowptr, colids, args, n_rows=32):
+    """After the timed region: one more minibatch, checked on sampled rows (the batch's largest hubs and zero-degree rows
+    included) against the CPU oracle's row function applied to the downloaded pre-step matrix, bit for bit; rows outside the
+    minibatch must not change.  -> number of rows verified (raises on a mismatch)."""
+    from oracle import oracle as O
+    n = len(rowptr) - 1
+    math = {5: 5, 8: 5, 11: 5, 6: 6, 9: 6}.get(args.option)
+    if math is None:
+        return None  # option 7's walks are per epoch: covered by the tests
+    deg = np.diff(rowptr.astype(np.int64))
+    before = eng.get_embeddings()
+    rng = np.random.default_rng(2)
+    lo = (n // 2 // args.batch) * args.batch
+    hi = min(lo + args.batch, n)
+    ids = rng.integers(0, n - 1, 5).astype(np.uint32)
+    eng.minibatch_step(args.option, lo, hi, ids, 5, 0.02)
+    after = eng.get_embeddings()
+    chunk = eng.get_param("hub_chunk")
+    rows = np.concatenate([rng.integers(lo, hi, n_rows - 8), lo + np.argsort(deg[lo:hi])[-4:], lo + np.flatnonzero(deg[lo:hi] == 0)[:4]])
+    for i in rows:
+        want = O.row(math, rowptr, colids, before, int(i), ids, 0.02, order=O.ORDER_TREE, chunk=chunk)
+        if not np.array_equal(after[i], want):
+            raise SystemExit("bench: row %d (degree %d) of the verification minibatch differs from the oracle by %g"
+                             % (i, deg[i], float(np.abs(after[i] - want).max())))
+    if not (np.array_equal(after[:lo], before[:lo]) and np.array_equal(after[hi:], before[hi:])):
+        raise SystemExit("bench: the verification minibatch changed rows outside [%d,%d)" % (lo, hi))
+    return int(len(rows))
 
 
 def kernel_name(args, pushing):
@@ -153,8 +216,8 @@ def main():
     ap.add_argument("--option", type=int, default=5)
     ap.add_argument("--hub-chunk", type=int, default=-1)
     ap.add_argument("--param", action="append", default=[], help="engine tunable name=value (repeatable)")
-    ap.add_argument("--cpu-scale", type=int, default=17)
-    ap.add_argument("--cpu-iters", type=int, default=8)
+    ap.add_argument("--cpu-scale", type=int, default=20, help="cpu_baseline graph: RMAT scale (20 = the benchmark's own 15.7 M-edge graph)")
+    ap.add_argument("--cpu-iters", type=int, default=16, help="cpu_baseline: epochs of the reference on the large graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange", choices=["push", "allgather", "need"], default="push",
                     help="N>1: push = the engine's own xGMI exchange (rows stored into the reading peers' HBM by a HIP kernel); "
@@ -173,6 +236,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="drive even a single rank through the multi-GPU path (RCCL group of 1): self-test")
     ap.add_argument("--extra-batches", type=str, default="256,4096,16384,262144", help="N=1: comma list of further batch sizes to time (reported under 'extra')")
     ap.add_argument("--dist-extra-batches", type=str, default="262144", help="N>1: the same for the sharded run (fewer, larger exchanges)")
+    ap.add_argument("--verify-rows", type=int, default=32, help="N=1: sampled rows of one more minibatch checked against the CPU oracle after the timed region (0 = skip)")
+    ap.add_argument("--config5-scale", type=int, default=24, help="also measure BASELINE configs[4] (RMAT of this scale, option 11) and report it under 'extra' (0 = skip)")
+    ap.add_argument("--config5-batch", type=int, default=1048576)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -200,7 +266,13 @@ def main():
         pre_dev = 0 if args.dist_backend == "gloo" else local_rank
         # where the ranks' children meet: all ranks are children of one launcher (torch.distributed.run), whose pid makes
         # the name unique to this launch; with another launcher the children time out and the run falls back
-        meet = "/tmp/f2v_preflight_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
+        # (the ranks cannot hand each other a mkdtemp name before they can talk: a private per-user parent directory instead)
+        parent = os.path.join(tempfile.gettempdir(), "f2v_preflight_uid%d" % os.getuid())
+        os.makedirs(parent, mode=0o700, exist_ok=True)
+        st = os.lstat(parent)
+        if st.st_uid != os.getuid() or (st.st_mode & 0o077) or not os.path.isdir(parent) or os.path.islink(parent):
+            raise SystemExit("bench: %s is not a private directory of this user" % parent)
+        meet = os.path.join(parent, "%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
         try:
             r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ipc_preflight.py"), str(pre_dev), str(rank), str(world), meet,
                                 str(mbytes), "60"], timeout=150, stdout=subprocess.DEVNULL)
@@ -245,95 +317,13 @@ def main():
         if rank == 0:
             load_graph(args.scale, 16, 1)
         dist.barrier(group=host_group) if host_group is not None else dist.barrier()
-    rowptr, colids = load_graph(args.scale, 16, 1)
-    n, nnz = len(rowptr) - 1, len(colids)
-    note(rank, "graph ready: n=%d nnz=%d" % (n, nnz))
-    eng = F.Engine(rowptr, colids, args.dim, device=local_rank)
-    if args.hub_chunk >= 0:
-        eng.set_param("hub_chunk", args.hub_chunk)
-    for kv in args.param:
-        k, v = kv.split("=")
-        eng.set_param(k, int(v))
-    eng.srand(1)
-    eng.init_embeddings(F._lib.INIT_SYMMETRIC if args.option in (5, 8, 11) else F._lib.INIT_UNIT)
-    note(rank, "engine ready, embeddings initialised")
-
-    def barrier():
-        eng.synchronize()
+    def sync_all():
         if use_dist:
             if args.dist_backend == "nccl":
                 torch.cuda.synchronize()
             dist.barrier()
             if args.dist_backend == "nccl":
                 torch.cuda.synchronize()
-
-    state = {"exchange": args.exchange, "comm": None, "note": getattr(args, "preflight_note", None)}
-
-    def make_comm():
-        """The exchange this run uses; the push exchange is attached (and self-tested) here, once."""
-        if state["comm"] is not None:
-            return state["comm"]
-        ex = state["exchange"]
-        if ex == "push":
-            comm = fdist.PushExchange(dist, rank, world, group=host_group)
-            try:
-                comm.attach(eng)
-                note(rank, "push exchange attached, self-test passed")
-            except Exception as exn:  # raised on every rank alike (the ranks agree inside attach)
-                state["note"] = "push exchange unavailable (%s): fell back to the RCCL all-gather" % (str(exn)[:200],)
-                log("bench[rank %d]: %s" % (rank, state["note"]))
-                state["exchange"] = ex = "allgather"
-        if ex == "allgather":
-            comm = (fdist.HostStageComm(dist, rank, world) if args.dist_backend == "gloo"
-                    else fdist.NcclStageComm(dist, rank, world, local_rank, host_group=host_group))
-        elif ex == "need":
-            comm = (fdist.NeedExchange(dist, rank, world, backend="host") if args.dist_backend == "gloo"
-                    else fdist.NeedExchange(dist, rank, world, device=local_rank, backend="device"))
-        state["comm"] = comm
-        return comm
-
-    schedule = []  # every (epochs, batch) trained so far: the verification replays it on one engine
-
-    def run_epochs(k, batch):
-        """-> per-rank statistics of these k epochs (launches, algorithmic bytes, device seconds where known)."""
-        schedule.append((k, batch))
-        if not use_dist:
-            eng.train(args.option, k, batch, 5, 0.02, 0)
-            return eng.stats()
-        s0 = eng.stats()
-        comm = make_comm()
-        fdist.ShardedTrainer(eng, rank, world, comm, exchange_when_single=True).train(args.option, k, batch, 5, 0.02, 0)
-        s1 = eng.stats()
-        if state["exchange"] == "push":
-            st = dict(s1)  # f2v_train_sharded restarts the statistics like f2v_train
-        else:
-            st = {key: s1[key] - s0[key] for key in s1}
-        st["device_seconds"] = None  # the sharded loop is timed by the wall clock below
-        return st
-
-    def settle(batch):
-        """Same workload, untimed, until the device has been under steady load for --settle-ms."""
-        if args.settle_ms <= 0:
-            return 0
-        run_epochs(2, batch)  # launch plans are built here, on the host: not load yet
-        eng.synchronize()
-        done, t0 = 2, time.perf_counter()
-        while max_over_ranks((time.perf_counter() - t0) * 1e3) < args.settle_ms and done < 1000:
-            run_epochs(4, batch)
-            eng.synchronize()
-            done += 4
-        return done
-
-    def timed(k, w, batch):
-        state["settle_epochs"] = settle(batch)
-        if w > 0:
-            run_epochs(w, batch)
-        barrier()
-        t0 = time.perf_counter()
-        st = run_epochs(k, batch)
-        barrier()
-        dt = max_over_ranks(time.perf_counter() - t0)
-        return dt, st
 
     def max_over_ranks(x):
         if not use_dist:
@@ -342,71 +332,190 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    def tune_push():
-        """Untimed: which of the two push variants is faster here?  Every rank sees the same (max-over-ranks) times."""
-        if args.push_fused != "auto":
-            eng.set_param("push_fused", int(args.push_fused))
-            return
-        run_epochs(1, args.batch)  # launch plans and reader masks exist from here on
-        note(rank, "first sharded epoch done")
-        settle(args.batch)         # both variants are timed on a GPU that has left the power-management transient behind
-        took = {1: float("inf"), 0: float("inf")}
-        for fused in (1, 0, 1, 0):  # alternating, best of two each
-            eng.set_param("push_fused", fused)
-            barrier()
-            t0 = time.perf_counter()
-            run_epochs(5, args.batch)
-            barrier()
-            took[fused] = min(took[fused], max_over_ranks(time.perf_counter() - t0) / 5)
-        best = 1 if took[1] <= took[0] else 0
-        eng.set_param("push_fused", best)
-        note(rank, "push variants timed: fused %.3f ms, separate kernel %.3f ms per epoch" % (took[1] * 1e3, took[0] * 1e3))
-        state["tuned"] = {"push_fused": best, "ms_per_epoch_fused": took[1] * 1e3, "ms_per_epoch_separate_kernel": took[0] * 1e3}
-
-    def verify(schedule):
-        """Every rank: the same epochs on ONE engine (no sharding, no exchange) must give this replica bit for bit."""
-        ref = F.Engine(rowptr, colids, args.dim, device=local_rank)
-        for kv in args.param:
-            pk, pv = kv.split("=")
-            if not pk.startswith("push_"):
-                ref.set_param(pk, int(pv))
-        ref.set_param("hub_chunk", eng.get_param("hub_chunk"))  # the chunk is part of the summation order
-        ref.srand(1)
-        ref.init_embeddings(F._lib.INIT_SYMMETRIC if args.option in (5, 8, 11) else F._lib.INIT_UNIT)
-        for i, (k, b) in enumerate(schedule):
-            try:
-                ref.train(args.option, k, b, 5, 0.02, 0)
-            except Exception:
-                note(rank, "single-GPU replay failed in call %d of %d (%d epochs at batch %d)" % (i, len(schedule), k, b))
-                raise
-        same = bool(np.array_equal(ref.get_embeddings(), eng.get_embeddings()))
-        ref.close()
-        t = torch.tensor([1 if same else 0], dtype=torch.int32, device="cuda" if args.dist_backend == "nccl" else "cpu")
+    def all_ranks_agree(flag):
+        if not use_dist:
+            return bool(flag)
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(t.item())
 
-    if use_dist and world > 1 and state["exchange"] == "push":
-        make_comm()
-        if state["exchange"] == "push":
-            tune_push()
-    dt, st = timed(args.steps, args.warmup, args.batch)
+    class Session:
+        """One engine on one graph / option: epochs (sharded over the ranks when N > 1), timing, verification."""
+
+        def __init__(self, rowptr, colids, option, exchange, note_text=None):
+            self.rowptr, self.colids, self.option = rowptr, colids, option
+            self.n, self.nnz = len(rowptr) - 1, len(colids)
+            self.init_kind = F._lib.INIT_SYMMETRIC if option in (5, 8, 11) else F._lib.INIT_UNIT
+            self.eng = F.Engine(rowptr, colids, args.dim, device=local_rank)
+            if args.hub_chunk >= 0:
+                self.eng.set_param("hub_chunk", args.hub_chunk)
+            for kv in args.param:
+                k, v = kv.split("=")
+                self.eng.set_param(k, int(v))
+            self.eng.set_param("count_compulsory", 1)
+            self.state = {"exchange": exchange, "comm": None, "note": note_text}
+            self.schedule = []  # every (epochs, batch) trained so far: the verification replays it on one engine
+            self.reset()
+
+        def reset(self):
+            self.eng.srand(1)
+            self.eng.init_embeddings(self.init_kind)
+            del self.schedule[:]
+
+        def barrier(self):
+            self.eng.synchronize()
+            sync_all()
+
+        def make_comm(self):
+            """The exchange this run uses; the push exchange is attached (and self-tested) here, once."""
+            st = self.state
+            if st["comm"] is not None:
+                return st["comm"]
+            ex = st["exchange"]
+            if ex == "push":
+                comm = fdist.PushExchange(dist, rank, world, group=host_group)
+                try:
+                    comm.attach(self.eng)
+                    note(rank, "push exchange attached, self-test passed")
+                except Exception as exn:  # raised on every rank alike (the ranks agree inside attach)
+                    st["note"] = "push exchange unavailable (%s): fell back to the RCCL all-gather" % (str(exn)[:200],)
+                    log("bench[rank %d]: %s" % (rank, st["note"]))
+                    st["exchange"] = ex = "allgather"
+            if ex == "allgather":
+                comm = (fdist.HostStageComm(dist, rank, world) if args.dist_backend == "gloo"
+                        else fdist.NcclStageComm(dist, rank, world, local_rank, host_group=host_group))
+            elif ex == "need":
+                comm = (fdist.NeedExchange(dist, rank, world, backend="host") if args.dist_backend == "gloo"
+                        else fdist.NeedExchange(dist, rank, world, device=local_rank, backend="device"))
+            st["comm"] = comm
+            return comm
+
+        def run_epochs(self, k, batch):
+            """-> per-rank statistics of these k epochs (launches, bytes, device seconds where known)."""
+            self.schedule.append((k, batch))
+            eng = self.eng
+            if not use_dist:
+                eng.train(self.option, k, batch, 5, 0.02, 0)
+                return eng.stats()
+            s0 = eng.stats()
+            comm = self.make_comm()
+            fdist.ShardedTrainer(eng, rank, world, comm, exchange_when_single=True).train(self.option, k, batch, 5, 0.02, 0)
+            s1 = eng.stats()
+            if self.state["exchange"] == "push":
+                st = dict(s1)  # f2v_train_sharded restarts the statistics like f2v_train
+            else:
+                st = {key: s1[key] - s0[key] for key in s1}
+            st["device_seconds"] = None  # the sharded loop is timed by the wall clock
+            return st
+
+        def settle(self, batch):
+            """Same workload, untimed, until the device has been under steady load for --settle-ms."""
+            if args.settle_ms <= 0:
+                return 0
+            self.run_epochs(2, batch)  # launch plans are built here, on the host: not load yet
+            self.eng.synchronize()
+            done, t0 = 2, time.perf_counter()
+            while max_over_ranks((time.perf_counter() - t0) * 1e3) < args.settle_ms and done < 1000:
+                self.run_epochs(4, batch)
+                self.eng.synchronize()
+                done += 4
+            return done
+
+        def timed(self, k, w, batch):
+            self.state["settle_epochs"] = self.settle(batch)
+            if w > 0:
+                self.run_epochs(w, batch)
+            self.barrier()
+            t0 = time.perf_counter()
+            st = self.run_epochs(k, batch)
+            self.barrier()
+            dt = max_over_ranks(time.perf_counter() - t0)
+            return dt, st
+
+        def tune_push(self, batch):
+            """Untimed: which of the two push variants is faster here?  Every rank sees the same (max-over-ranks) times."""
+            eng = self.eng
+            if args.push_fused != "auto":
+                eng.set_param("push_fused", int(args.push_fused))
+                return
+            self.run_epochs(1, batch)  # launch plans and reader masks exist from here on
+            note(rank, "first sharded epoch done")
+            self.settle(batch)         # both variants are timed on a GPU that has left the power-management transient behind
+            took = {1: float("inf"), 0: float("inf")}
+            for fused in (1, 0, 1, 0):  # alternating, best of two each
+                eng.set_param("push_fused", fused)
+                self.barrier()
+                t0 = time.perf_counter()
+                self.run_epochs(5, batch)
+                self.barrier()
+                took[fused] = min(took[fused], max_over_ranks(time.perf_counter() - t0) / 5)
+            best = 1 if took[1] <= took[0] else 0
+            eng.set_param("push_fused", best)
+            note(rank, "push variants timed: fused %.3f ms, separate kernel %.3f ms per epoch" % (took[1] * 1e3, took[0] * 1e3))
+            self.state["tuned"] = {"push_fused": best, "ms_per_epoch_fused": took[1] * 1e3, "ms_per_epoch_separate_kernel": took[0] * 1e3}
+
+        def verify_replica(self):
+            """Every rank: the same epochs on ONE engine (no sharding, no exchange) must give this replica bit for bit."""
+            ref = F.Engine(self.rowptr, self.colids, args.dim, device=local_rank)
+            for kv in args.param:
+                pk, pv = kv.split("=")
+                if not pk.startswith("push_"):
+                    ref.set_param(pk, int(pv))
+            ref.set_param("hub_chunk", self.eng.get_param("hub_chunk"))  # the chunk is part of the summation order
+            ref.srand(1)
+            ref.init_embeddings(self.init_kind)
+            for i, (k, b) in enumerate(self.schedule):
+                try:
+                    ref.train(self.option, k, b, 5, 0.02, 0)
+                except Exception:
+                    note(rank, "single-GPU replay failed in call %d of %d (%d epochs at batch %d)" % (i, len(self.schedule), k, b))
+                    raise
+            same = bool(np.array_equal(ref.get_embeddings(), self.eng.get_embeddings()))
+            ref.close()
+            return all_ranks_agree(same)
+
+        def close(self):
+            if use_dist and self.state["exchange"] == "push" and self.state["comm"] is not None:
+                self.state["comm"].detach(self.eng)
+            self.eng.close()
+
+    failed = []  # anything here makes the line carry "failed": true and the process exit non-zero
+
+    def measure(sess, steps, warmup, batch, tune):
+        """The timed region + (N > 1) the bit-for-bit replica check.  A push replica that differs from the single-GPU
+        run is a FAILURE of the run; the RCCL re-measurement afterwards is additional data, not a substitute."""
+        if use_dist and world > 1 and sess.state["exchange"] == "push":
+            sess.make_comm()
+            if sess.state["exchange"] == "push" and tune:
+                sess.tune_push(batch)
+        dt, st = sess.timed(steps, warmup, batch)
+        verified = None
+        if use_dist and not args.no_verify:
+            verified = sess.verify_replica()
+            note(rank, "replica compared with a single-GPU run of the same %d epochs: %s" % (sum(k for k, _ in sess.schedule), "identical" if verified else "DIFFERENT"))
+            if not verified:
+                failed.append("%s exchange: replica differs from the single-GPU run (option %d, batch %d, n=%d)" % (sess.state["exchange"], sess.option, batch, sess.n))
+                if sess.state["exchange"] == "push":
+                    sess.state["note"] = "FAILED: the push exchange gave a replica that differs from the single-GPU run; the numbers below were measured again over the RCCL all-gather"
+                    log("bench[rank %d]: %s" % (rank, sess.state["note"]))
+                    sess.state["comm"].detach(sess.eng)
+                    sess.state["comm"], sess.state["exchange"] = None, "allgather"
+                    sess.reset()
+                    dt, st = sess.timed(steps, warmup, batch)
+                    verified_again = sess.verify_replica()
+                    if not verified_again:
+                        failed.append("RCCL all-gather: replica differs from the single-GPU run too")
+        return dt, st, verified
+
+    rowptr, colids = load_graph(args.scale, 16, 1)
+    n, nnz = len(rowptr) - 1, len(colids)
+    note(rank, "graph ready: n=%d nnz=%d" % (n, nnz))
+    sess = Session(rowptr, colids, args.option, args.exchange, getattr(args, "preflight_note", None))
+    eng, state = sess.eng, sess.state
+    note(rank, "engine ready, embeddings initialised")
+    dt, st, verified = measure(sess, args.steps, args.warmup, args.batch, tune=True)
     main_settle = state["settle_epochs"]
     note(rank, "timed region done: %.3f ms per epoch" % (dt / args.steps * 1e3))
-    verified = None
-    if use_dist and not args.no_verify:
-        verified = verify(schedule)
-        note(rank, "replica compared with a single-GPU run of the same %d epochs: %s" % (sum(k for k, _ in schedule), "identical" if verified else "DIFFERENT"))
-        if not verified and state["exchange"] == "push":
-            # never report a number for wrong results: redo the whole measurement over the RCCL all-gather
-            state["note"] = "push exchange gave a replica that differs from the single-GPU run: measured again over the RCCL all-gather"
-            log("bench[rank %d]: %s" % (rank, state["note"]))
-            state["comm"].detach(eng)
-            state["comm"], state["exchange"] = None, "allgather"
-            eng.srand(1)
-            eng.init_embeddings(F._lib.INIT_SYMMETRIC if args.option in (5, 8, 11) else F._lib.INIT_UNIT)
-            del schedule[:]
-            dt, st = timed(args.steps, args.warmup, args.batch)
-            verified = verify(schedule)
     # rForce2Vec attracts along 5 walk samples per vertex, not along the CSR's nonzeros (SURVEY 8d)
     units = 5 * n if args.option in (7, 10) else nnz
     value = units * args.steps / dt
@@ -436,62 +545,117 @@ def main():
             ps = eng.push_stats()
             res["config"]["rows_pushed_over_allgather_rows"] = ps["rows_pushed"] / max(ps["rows_allgather"], 1)
     if st is not None:
-        # dominant kernel = qstep_kernel, one launch per minibatch; launch time from HIP events on the
-        # engine's stream around the epoch loop (f2v_train), algorithmic bytes per SURVEY 8d.
-        # N > 1: rank 0's share of the bytes over the wall time of the sharded loop (exchange included).
-        per_launch = st["algorithmic_bytes"] / max(st["step_launches"], 1)
-        t_launch = (st["device_seconds"] if st["device_seconds"] else dt) / max(st["step_launches"], 1)
-        ach = per_launch / t_launch * 1e-9
-        traffic = None
+        # dominant kernel = the step kernel, one launch per minibatch; launch time from HIP events on the engine's stream
+        # around the epoch loop (f2v_train).  N > 1: rank 0's share of the bytes over the wall time of the sharded loop.
+        launches = max(st["step_launches"], 1)
+        t_launch = (st["device_seconds"] if st["device_seconds"] else dt) / launches
+        comp = st["compulsory_bytes"] / launches
+        alg = st["algorithmic_bytes"] / launches
+        kname = kernel_name(args, use_dist and world > 1 and state["exchange"] == "push" and eng.get_param("push_fused"))
+        ach = comp / t_launch * 1e-9
+        roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "kernel": kname, "compulsory_bytes_per_launch": comp, "avg_launch_us": t_launch * 1e6, "launches": st["step_launches"],
+                "definition": "achieved = compulsory bytes per launch (distinct embedding rows read + rows written + neighbour ids + work items, "
+                              "counted by the engine) / average launch time; frac <= 1 by construction",
+                # SURVEY 8d's count charges EVERY neighbour row to HBM: a rate of useful bytes delivered to the CUs, served by L2 + Infinity Cache + HBM together
+                "algorithmic_bytes_per_launch": alg, "algorithmic_GBs": alg / t_launch * 1e-9}
         tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp):
+        if os.path.exists(tp) and not use_dist:
             try:
                 tj = json.load(open(tp))
-                if not use_dist and tj.get("batch") == args.batch and tj.get("scale") == args.scale and tj.get("dim") == args.dim:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                key = {"batch": args.batch, "scale": args.scale, "dim": args.dim, "option": args.option, "hub_chunk": eng.get_param("hub_chunk"),
+                       "kernel": kname, "library": F._lib.lib().f2v_version().decode()}
+                if all(tj.get(k) == v for k, v in key.items()):
+                    roof["traffic"] = tj.get("l2_miss_bytes_per_launch")
+                    roof["traffic_is"] = "bytes that left the XCDs' L2s per launch (PMC: TCC_EA0_RDREQ/WRREQ, calibrated): HBM + Infinity Cache, which rocprofv3 cannot split on gfx950"
+                    roof["l2_miss_GBs"] = roof["traffic"] / t_launch * 1e-9
+                    roof["l2_hit_rate"] = tj.get("l2_hit_rate")
+                    roof["hbm_bytes_per_launch_between"] = [comp, roof["traffic"]]
+                else:
+                    roof["traffic_note"] = "profiles/traffic.json was collected for another workload / kernel / library build: not applied"
             except Exception:
                 pass
-        res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": traffic, "kernel": kernel_name(args, use_dist and world > 1 and state["exchange"] == "push" and eng.get_param("push_fused")), "algorithmic_bytes_per_launch": per_launch,
-                           "avg_launch_us": t_launch * 1e6, "launches": st["step_launches"],
-                           # frac counts ALGORITHMIC bytes, so XCD-L2 hits on hub rows can push it past 1; what actually crossed
-                           # the fabric (PMC) over the same time is the honest HBM utilisation
-                           "hbm_frac_from_traffic": (traffic / t_launch * 1e-9 / HBM_PEAK_GBS) if traffic else None}
         if not use_dist:
             import ctypes
             g = ctypes.c_double()
-            if F._lib.lib().f2v_diag_stream_copy(local_rank, 1 << 30, 5, ctypes.byref(g)) == 0:
-                res["roofline"]["stream_copy_GBs_on_this_box"] = g.value  # 1-GiB copy kernel, read + written bytes
+            L = F._lib.lib()
+            if L.f2v_diag_stream_copy(local_rank, 1 << 30, 5, ctypes.byref(g)) == 0:
+                roof["stream_copy_GBs_on_this_box"] = g.value   # 1-GiB copy, read + written bytes
+            if L.f2v_diag_gather_rate(local_rank, 4 << 30, 2, ctypes.byref(g)) == 0:
+                roof["row_gather_from_hbm_GBs_on_this_box"] = g.value  # random 512-B rows of a 4-GiB table, each once
+            if L.f2v_diag_gather_rate(local_rank, 64 << 20, 2, ctypes.byref(g)) == 0:
+                roof["row_gather_from_infinity_cache_GBs_on_this_box"] = g.value  # the same from a 64-MiB table
+        res["roofline"] = roof
+    if not use_dist and args.verify_rows > 0:
+        res["config"]["verified_rows"] = verify_rows(F, eng, rowptr, colids, args, args.verify_rows)
+        note(rank, "verification minibatch: %s sampled rows bit-identical to the oracle" % res["config"]["verified_rows"])
+    extra = {}
     if rank == 0 and not use_dist:
-        extra = {}
         for b in [int(x) for x in args.extra_batches.split(",") if x]:
-            dtb, stb = timed(max(1, args.steps // 2), 1, b)
             k = max(1, args.steps // 2)
+            dtb, stb = sess.timed(k, 1, b)
             extra["batch_%d" % b] = {"edges_per_s": units * k / dtb, "ms_per_epoch": dtb / k * 1e3,
-                                     "hbm_GBs": stb["algorithmic_bytes"] / stb["device_seconds"] * 1e-9}
-        if extra:
-            res["extra"] = extra
+                                     "algorithmic_GBs": stb["algorithmic_bytes"] / stb["device_seconds"] * 1e-9,
+                                     "compulsory_GBs": stb["compulsory_bytes"] / stb["device_seconds"] * 1e-9}
     if use_dist and world > 1:
-        extra = {}
         for b in [int(x) for x in args.dist_extra_batches.split(",") if x]:
             k = max(1, args.steps // 2)
-            dtb, _ = timed(k, 1, b)
+            dtb, _ = sess.timed(k, 1, b)
             extra["batch_%d" % b] = {"edges_per_s": units * k / dtb, "ms_per_epoch": dtb / k * 1e3}
-        if extra:
-            res["extra"] = extra
+        if extra and not args.no_verify:  # everything trained since the first check is checked too
+            ok = sess.verify_replica()
+            extra["replicas_bit_identical_to_1gpu_run"] = ok
+            if not ok:
+                failed.append("extra batches: replica differs from the single-GPU run")
+    sess.close()
+    del sess, eng
+    if args.config5_scale > 0:
+        # BASELINE configs[4]: RMAT scale-24, option 11, D = 128, minibatches of 1 M rows -- the size at which a minibatch is
+        # milliseconds of work per rank, i.e. where the strong-scaling target lives.  Same measurement, same checks.
+        if not use_dist or rank == 0:
+            load_graph(args.config5_scale, 16, 1)
+        sync_all()
+        rp5, ci5 = load_graph(args.config5_scale, 16, 1)
+        note(rank, "config 5 graph ready: n=%d nnz=%d" % (len(rp5) - 1, len(ci5)))
+        s5 = Session(rp5, ci5, 11, state["exchange"] if use_dist else args.exchange)
+        k5 = max(2, min(args.steps, 5))
+        opt_saved, args.option = args.option, 11
+        dt5, st5, ver5 = measure(s5, k5, 1, args.config5_batch, tune=False)
+        c5 = {"workload": "RMAT scale-%d (n=%d, nnz=%d), option 11, D=%d, batch=%d" % (args.config5_scale, len(rp5) - 1, len(ci5), args.dim, args.config5_batch),
+              "edges_per_s": len(ci5) * k5 / dt5, "ms_per_epoch": dt5 / k5 * 1e3, "epochs": k5, "hub_chunk": s5.eng.get_param("hub_chunk")}
+        if use_dist:
+            c5["exchange"] = s5.state["exchange"]
+            c5["replicas_bit_identical_to_1gpu_run"] = ver5
+            if s5.state["note"]:
+                c5["note"] = s5.state["note"]
+        else:
+            c5["compulsory_GBs"] = st5["compulsory_bytes"] / st5["device_seconds"] * 1e-9
+            c5["algorithmic_GBs"] = st5["algorithmic_bytes"] / st5["device_seconds"] * 1e-9
+            if args.verify_rows > 0:
+                a5 = argparse.Namespace(**vars(args))
+                a5.batch = args.config5_batch
+                c5["verified_rows"] = verify_rows(F, s5.eng, rp5, ci5, a5, args.verify_rows)
+        args.option = opt_saved
+        extra["config5_rmat%d_option11" % args.config5_scale] = c5
+        s5.close()
+        del s5
+    if extra:
+        res["extra"] = extra
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             res["cpu_baseline"] = cpu_baseline(args)
         except Exception as ex:  # the baseline is reported, never required for the GPU number
             res["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": os.cpu_count(), "kind": "reference", "sample": "failed: %r" % (ex,)}
-    if use_dist and state["exchange"] == "push" and state["comm"] is not None:
-        state["comm"].detach(eng)
-    eng.close()
+    if failed:
+        res["failed"] = True
+        res["failures"] = failed
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(res), flush=True)
+    if failed:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

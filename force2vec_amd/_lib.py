@@ -18,7 +18,7 @@ f32p = C.POINTER(C.c_float)
 class Stats(C.Structure):
     _fields_ = [("step_launches", C.c_uint64), ("rows", C.c_uint64), ("nnz", C.c_uint64),
                 ("algorithmic_bytes", C.c_uint64), ("device_seconds", C.c_double),
-                ("hub_rows", C.c_uint64), ("hub_chunks", C.c_uint64)]
+                ("hub_rows", C.c_uint64), ("hub_chunks", C.c_uint64), ("compulsory_bytes", C.c_uint64)]
 
 
 # every entry point declared in include/f2v.h: name -> (restype, argtypes)
@@ -75,6 +75,7 @@ SIGNATURES = {
     "f2v_sm_table": (C.c_int, [f32p]),
     "f2v_diag_ipc_preflight": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint64, C.c_double]),
     "f2v_diag_stream_copy": (C.c_int, [C.c_int, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
+    "f2v_diag_gather_rate": (C.c_int, [C.c_int, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
 }
 
 # include/f2v_test.h: only in libf2v_selftest.so (the same sources built with -DF2V_TEST_HOOKS), for tests/ and tools/

@@ -48,6 +48,7 @@ struct Plan {
     size_t fin_off[kMaxFinLevels] = {};
     uint32_t fin_cnt[kMaxFinLevels] = {};
     uint64_t nnz = 0;
+    uint64_t compulsory = 0;  // bytes this launch must move even with perfect caching inside the launch ("count_compulsory")
 };
 
 // what a rank hands its peers (f2v_push_export): F2V_PUSH_EXPORT_BYTES bytes
@@ -55,7 +56,8 @@ struct PushExport {
     hipIpcMemHandle_t x[2], flags;  // landing-buffer mode: x[0] is the landing buffer, x[1] unused
     uint32_t magic, n, D, cur;
     uint32_t landing, landing_cap;
-    char reserved[F2V_PUSH_EXPORT_BYTES - 3 * sizeof(hipIpcMemHandle_t) - 24];
+    char bus_id[16];  // PCI bus id of the exporting rank's GPU: ranks that share a card run without "piece_affinity"
+    char reserved[F2V_PUSH_EXPORT_BYTES - 3 * sizeof(hipIpcMemHandle_t) - 24 - 16];
 };
 static_assert(sizeof(PushExport) == F2V_PUSH_EXPORT_BYTES, "export blob layout");
 static_assert(kMaxRanks == F2V_PUSH_MAX_RANKS, "rank limit");
@@ -104,6 +106,11 @@ struct f2v_ctx {
     bool fast_rng = false;        // non-parity mode: device-side init and option-7 walks (counter-based RNG)
     uint64_t fast_seed = 1, fast_epoch = 0;
     int rows_in_flight = 4;
+    bool piece_affinity = true;    // hub pieces are placed on the XCD that owns their neighbours' id range (see plan_for)
+    bool shared_card = false;      // a peer of the push exchange runs on the same GPU: placement goes back to same-XCD groups
+    bool count_compulsory = false;  // plans also count their compulsory bytes (f2v_stats.compulsory_bytes; costs O(nnz) per new plan)
+    std::vector<uint32_t> seen_stamp;  // ... with this marker array
+    uint32_t stamp = 0;
     bool use_graph = false;  // f2v_train replays one hipGraph per epoch parity instead of launching eagerly
     f2v_stats stats{};
     // multi-GPU push exchange (include/f2v.h): peers' matrices and flags mapped through HIP IPC
@@ -237,7 +244,7 @@ const Plan &plan_for(f2v_ctx *c, uint32_t row_lo, uint32_t row_hi, bool walk) {
         // its node -- gets the class that has been given the fewest neighbours so far (a giant hub thus spreads over all XCDs).
         std::vector<Item> queue[kXcds];
         std::vector<FinItem> nq[kXcds];
-        uint64_t load[kXcds] = {};  // neighbours given to every class so far: a group goes to the lightest one
+        uint64_t load[kXcds] = {}, aload[kXcds] = {};  // neighbours given to every class so far: a group goes to the lightest one
         for (const Node &nd : cur) {
             const uint32_t rp = c->rowptr[nd.row], deg = c->rowptr[nd.row + 1] - rp;
             const uint32_t G = c->fanin < 2 ? nd.n : c->fanin;
@@ -250,7 +257,23 @@ const Plan &plan_for(f2v_ctx *c, uint32_t row_lo, uint32_t row_hi, bool walk) {
                 load[cls] += std::min(deg, k1 * c->chunk) - k0 * c->chunk;
                 for (uint32_t k = k0; k < k1; k++) {
                     const uint32_t b = k * c->chunk, e = std::min(deg, b + c->chunk);
-                    queue[cls].push_back(Item{nd.row, rp + b, e - b, kItemPartial | (k == 0 ? kItemFirst : 0u) | (k == nd.n - 1 ? kItemLast : 0u) | (nd.in_slot + k)});
+                    // "piece_affinity" (DESIGN.md section 3): a piece goes to the XCD that owns the id range of its (ascending)
+                    // neighbours -- the lightest of the XCDs whose ranges it touches: midpoints alone leave the outer ranges short
+                    // of work and cost 40 % -- so that every L2 caches an eighth of the matrix instead of all eight the same
+                    // hubs: RMAT-20, batch 65536: L2 hit rate 0.31 -> 0.42, L2-miss reads -17 %, epoch time -7...-10 %.
+                    // Placement only: bits do not change.  The group's node stays in class `cls`, so it may now wait for other
+                    // XCDs' workgroups: fine inside one process (index order), not with a second process on the card that could
+                    // fill an XCD with ITS waiting nodes -- ranks that share a card are detected (f2v_push_attach) and keep
+                    // the same-XCD groups.
+                    uint32_t pc = cls;
+                    if (c->piece_affinity && !c->shared_card) {
+                        const uint32_t c0 = (uint32_t)(((uint64_t)c->colids[rp + b] * kXcds) / c->n), c1 = (uint32_t)(((uint64_t)c->colids[rp + e - 1] * kXcds) / c->n);
+                        pc = c0;
+                        for (uint32_t q = c0 + 1; q <= c1; q++)
+                            if (aload[q] < aload[pc]) pc = q;
+                        aload[pc] += e - b;
+                    }
+                    queue[pc].push_back(Item{nd.row, rp + b, e - b, kItemPartial | (k == 0 ? kItemFirst : 0u) | (k == nd.n - 1 ? kItemLast : 0u) | (nd.in_slot + k)});
                 }
                 nq[cls].push_back(FinItem{nd.in_slot + k0, k1 - k0, nout == 1 ? kFinToStage : slots + o, nd.row});
             }
@@ -323,6 +346,27 @@ const Plan &plan_for(f2v_ctx *c, uint32_t row_lo, uint32_t row_hi, bool walk) {
         slots++;
     }
     p.n_slots = slots;
+    if (c->count_compulsory) {
+        // Compulsory bytes of this launch: every DISTINCT embedding row it reads (its own rows and their neighbours) once,
+        // every row it writes once, its neighbour ids and work items once -- what would still cross HBM if everything
+        // read twice inside the launch came from a cache the second time.  (The ns sampled rows, the partial sums of split
+        // rows and rowptr are left out: a lower bound.)
+        if (c->seen_stamp.size() != c->n) { c->seen_stamp.assign(c->n, 0u); c->stamp = 0; }
+        if (++c->stamp == 0) { std::fill(c->seen_stamp.begin(), c->seen_stamp.end(), 0u); c->stamp = 1; }
+        const uint32_t st = c->stamp;
+        uint32_t *seen = c->seen_stamp.data();
+        uint64_t distinct = 0;
+        const uint32_t *ids = walk ? nullptr : c->colids.data();
+        for (uint32_t i = row_lo; i < row_hi; i++) {
+            if (seen[i] != st) { seen[i] = st; distinct++; }
+            if (!ids) continue;  // walk samples change every epoch: only the rows themselves are counted
+            for (uint32_t k = c->rowptr[i]; k < c->rowptr[i + 1]; k++) {
+                const uint32_t j = ids[k];
+                if (seen[j] != st) { seen[j] = st; distinct++; }
+            }
+        }
+        p.compulsory = distinct * 4ull * c->D + (uint64_t)(row_hi - row_lo) * 4ull * c->D + p.nnz * 4ull + (uint64_t)p.n_items * sizeof(Item);
+    }
     c->max_slots = std::max<size_t>(c->max_slots, slots);
     return c->plans.emplace(key, p).first->second;
 }
@@ -624,6 +668,7 @@ int launch_step(f2v_ctx *c, int math, uint32_t batch_lo, uint32_t batch_hi, uint
     c->stats.rows += rows;
     c->stats.nnz += plan.nnz;
     c->stats.algorithmic_bytes += plan.nnz * (4ull * c->D + 4) + rows * (8ull * c->D + 4) + (uint64_t)ns * (4ull * c->D + 4);
+    c->stats.compulsory_bytes += plan.compulsory;
     return F2V_OK;
 }
 
@@ -767,6 +812,7 @@ int push_detach(f2v_ctx *c) {
     c->push.local = false;
     c->push.rank = 0;
     c->push.world = 1;
+    if (c->shared_card) { c->shared_card = false; drop_plans(c); }
     return F2V_OK;
 }
 
@@ -1070,6 +1116,28 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
         c->use_graph = value != 0;
         return F2V_OK;
     }
+    if (!strcmp(name, "piece_affinity")) {
+        if (c->piece_affinity != (value != 0)) {
+            HIPC(hipSetDevice(c->device));
+            int rc = flush_pending(c);
+            if (rc != F2V_OK) return rc;
+            HIPC(hipStreamSynchronize(c->stream));
+            c->piece_affinity = value != 0;
+            drop_plans(c);
+        }
+        return F2V_OK;
+    }
+    if (!strcmp(name, "count_compulsory")) {
+        if (c->count_compulsory != (value != 0)) {
+            HIPC(hipSetDevice(c->device));
+            int rc = flush_pending(c);
+            if (rc != F2V_OK) return rc;
+            HIPC(hipStreamSynchronize(c->stream));
+            c->count_compulsory = value != 0;
+            drop_plans(c);
+        }
+        return F2V_OK;
+    }
     if (!strcmp(name, "rows_in_flight")) {
         if (value != 4 && value != 8) return fail(F2V_EINVAL, "rows_in_flight must be 4 or 8");
         c->rows_in_flight = (int)value;
@@ -1120,6 +1188,9 @@ int f2v_get_param(f2v_handle c, const char *name, int64_t *out) {
     if (!strcmp(name, "hub_fanin")) { *out = c->fanin; return F2V_OK; }
     if (!strcmp(name, "fast_rng")) { *out = c->fast_rng ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "use_graph")) { *out = c->use_graph ? 1 : 0; return F2V_OK; }
+    if (!strcmp(name, "count_compulsory")) { *out = c->count_compulsory ? 1 : 0; return F2V_OK; }
+    if (!strcmp(name, "piece_affinity")) { *out = c->piece_affinity ? 1 : 0; return F2V_OK; }
+    if (!strcmp(name, "shared_card")) { *out = c->shared_card ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "hub_chunk_auto")) { *out = c->chunk_auto ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "push_timeout_ms")) { *out = c->push.timeout_ms; return F2V_OK; }
     if (!strcmp(name, "push_fused")) { *out = c->push.fused ? 1 : 0; return F2V_OK; }
@@ -1469,7 +1540,7 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
         }
         // the host-side bookkeeping now stands where two executed epochs leave it; one epoch's statistics were counted twice
         f2v_stats one = c->stats;
-        one.step_launches /= 2; one.rows /= 2; one.nnz /= 2; one.algorithmic_bytes /= 2; one.hub_rows /= 2; one.hub_chunks /= 2;
+        one.step_launches /= 2; one.rows /= 2; one.nnz /= 2; one.algorithmic_bytes /= 2; one.hub_rows /= 2; one.hub_chunks /= 2; one.compulsory_bytes /= 2;
         HIPC(hipEventRecord(ev0, c->stream));
         for (uint32_t it = 0; it < iters; it++) {
             if (it >= 2)
@@ -1479,7 +1550,7 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
         }
         if (iters & 1) c->cur ^= 1;  // an odd number of epochs ends on the other matrix than the two captured ones did
         c->stats = one;
-        c->stats.step_launches *= iters; c->stats.rows *= iters; c->stats.nnz *= iters; c->stats.algorithmic_bytes *= iters;
+        c->stats.step_launches *= iters; c->stats.rows *= iters; c->stats.nnz *= iters; c->stats.algorithmic_bytes *= iters; c->stats.compulsory_bytes *= iters;
         c->stats.hub_rows *= iters; c->stats.hub_chunks *= iters;
         HIPC(hipStreamSynchronize(c->stream));
         for (int par = 0; par < 2; par++) { (void)hipGraphExecDestroy(exec[par]); (void)hipGraphDestroy(graph[par]); }
@@ -1611,6 +1682,11 @@ int f2v_push_export(f2v_handle c, void *handles_out) {
     e.cur = (uint32_t)c->cur;
     e.landing = c->push.landing ? 1u : 0u;
     e.landing_cap = c->push.landing_cap;
+    memset(e.bus_id, 0, sizeof e.bus_id);
+    {
+        char bus[64] = {};
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, c->device) == hipSuccess) strncpy(e.bus_id, bus, sizeof e.bus_id - 1);
+    }
     memcpy(handles_out, &e, sizeof e);
     c->push.exported = true;
     return F2V_OK;
@@ -1632,6 +1708,20 @@ int f2v_push_attach(f2v_handle c, uint32_t rank, uint32_t world, const void *all
         if ((e.landing != 0) != c->push.landing || (c->push.landing && e.landing_cap != c->push.landing_cap))
             return fail(F2V_ESTATE, "f2v_push_attach: rank %u exchanges through %s, this rank through %s (\"push_landing\" must agree)", r,
                         e.landing ? "a landing buffer" : "mapped matrices", c->push.landing ? "a landing buffer" : "mapped matrices");
+    }
+    {
+        PushExport me;
+        memcpy(&me, all + rank, sizeof me);
+        bool shared = false;
+        for (uint32_t r = 0; r < world; r++) {
+            PushExport e;
+            memcpy(&e, all + r, sizeof e);
+            if (r != rank && (me.bus_id[0] == 0 || !memcmp(e.bus_id, me.bus_id, sizeof me.bus_id))) shared = true;
+        }
+        if (shared != c->shared_card) {  // placement of the hub pieces depends on it
+            c->shared_card = shared;
+            drop_plans(c);
+        }
     }
     c->push.rank = rank;
     c->push.world = world;
@@ -1693,6 +1783,7 @@ int f2v_test_push_attach_local(f2v_handle c, uint32_t rank, uint32_t world, cons
         c->push.peer_landing[r] = all[r]->push.landing_buf;
         if (all[r]->push.landing != c->push.landing) return fail(F2V_ESTATE, "f2v_test_push_attach_local: \"push_landing\" must agree");
     }
+    if (!c->shared_card && world > 1) { c->shared_card = true; drop_plans(c); }
     c->push.rank = rank;
     c->push.world = world;
     c->push.attached = c->push.local = true;
@@ -1866,9 +1957,57 @@ int f2v_diag_ipc_preflight(int device, uint32_t rank, uint32_t world, const char
     return F2V_OK;
 }
 
+// Random-row gather ceiling of this card: every 512-byte row of a `table_bytes` table is fetched exactly once per pass, in
+// random order, with the step kernel's access pattern (16 lanes x dwordx4 per row, 4 rows in flight per item); enough
+// passes per launch to gather about 2 GiB.  Small tables measure the Infinity Cache / L2, tables far beyond 256 MiB the HBM.
+int f2v_diag_gather_rate(int device, uint64_t table_bytes, uint32_t reps, double *gbps_out) {
+    if (!gbps_out || table_bytes < (1u << 20) || table_bytes > (64ull << 30) || reps == 0) return fail(F2V_EINVAL, "f2v_diag_gather_rate: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(F2V_ENODEV, "no such HIP device");
+    HIPC(hipSetDevice(device));
+    const uint32_t rows = (uint32_t)(table_bytes / 512);
+    const uint32_t passes = (uint32_t)std::max<uint64_t>(1, (2ull << 30) / ((uint64_t)rows * 512));
+    const uint64_t n_ids = (uint64_t)rows * passes;
+    if (n_ids > 0xFFFFFFF0ull) return fail(F2V_EINVAL, "f2v_diag_gather_rate: table too large");
+    std::vector<uint32_t> ids(n_ids);
+    Rand g;
+    g.seed(11);
+    auto big = [&] { return ((uint64_t)g.next() << 31) | (uint64_t)g.next(); };
+    for (uint32_t i = 0; i < rows; i++) ids[i] = i;
+    for (uint32_t i = rows - 1; i > 0; i--) std::swap(ids[i], ids[(uint32_t)(big() % (i + 1))]);
+    for (uint32_t p = 1; p < passes; p++) {  // later passes: the same permutation under another random rotation and stride
+        const uint32_t rot = (uint32_t)(big() % rows);
+        for (uint32_t i = 0; i < rows; i++) ids[(size_t)p * rows + i] = ids[(i + rot) % rows] ^ 0u;
+    }
+    float *d_t = nullptr, *d_o = nullptr;
+    uint32_t *d_i = nullptr;
+    HIPC(hipMalloc((void **)&d_t, (size_t)rows * 512));
+    HIPC(hipMalloc((void **)&d_i, n_ids * sizeof(uint32_t)));
+    HIPC(hipMalloc((void **)&d_o, 64));
+    HIPC(hipMemset(d_t, 0, (size_t)rows * 512));
+    HIPC(hipMemcpy(d_i, ids.data(), n_ids * sizeof(uint32_t), hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    HIPC(hipEventCreate(&e0));
+    HIPC(hipEventCreate(&e1));
+    double best = 0.0;
+    for (uint32_t r = 0; r < reps + 2; r++) {
+        HIPC(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL((gather_calibration_kernel<2>), dim3(4096), dim3(256), 0, 0, d_t, d_i, (uint32_t)n_ids, d_o);
+        HIPC(hipEventRecord(e1, 0));
+        HIPC(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIPC(hipEventElapsedTime(&ms, e0, e1));
+        if (r >= 2 && ms > 0.f) best = std::max(best, (double)n_ids * 516.0 / (ms * 1e-3) * 1e-9);
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(d_t); (void)hipFree(d_i); (void)hipFree(d_o);
+    *gbps_out = best;
+    return F2V_OK;
+}
+
 // Streaming-copy ceiling of this card: `reps` copies of `bytes` (read + written = 2*bytes each), best rate in GB/s.
 int f2v_diag_stream_copy(int device, uint64_t bytes, uint32_t reps, double *gbps_out) {
-    if (!gbps_out || bytes < 4096 || reps == 0) return fail(F2V_EINVAL, "f2v_diag_stream_copy: bad argument");
+    if (!gbps_out || bytes < 4096 || reps == 0 || bytes / 16 / 1024 > 0x7FFFFFFFull) return fail(F2V_EINVAL, "f2v_diag_stream_copy: bad argument");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(F2V_ENODEV, "no such HIP device");
     HIPC(hipSetDevice(device));
@@ -1883,7 +2022,7 @@ int f2v_diag_stream_copy(int device, uint64_t bytes, uint32_t reps, double *gbps
     double best = 0.0;
     for (uint32_t r = 0; r < reps + 2; r++) {
         HIPC(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(stream_copy_kernel, dim3(8192), dim3(256), 0, 0, a, b, bytes / 16);
+        hipLaunchKernelGGL((stream_copy_kernel<4>), dim3((uint32_t)((bytes / 16 + 1023) / 1024)), dim3(256), 0, 0, (const f32x4_copy_t *)a, (f32x4_copy_t *)b, (uint64_t)(bytes / 16));
         HIPC(hipEventRecord(e1, 0));
         HIPC(hipEventSynchronize(e1));
         float ms = 0.f;

@@ -1087,8 +1087,7 @@ __global__ void fast_walks_kernel(const uint32_t *rowptr, const uint32_t *colids
     }
 }
 
-#ifdef F2V_TEST_HOOKS
-// PMC calibration: the step kernel's access pattern with a KNOWN byte count.  Every quarter-wave
+// PMC calibration and on-box gather ceiling (f2v_diag_gather_rate): the step kernel's access pattern with a KNOWN byte count.  Every quarter-wave
 // gathers whole 64*NB-float rows (NB x 16 lanes x dwordx4) named by `ids`, each row exactly once,
 // and folds them into a checksum so that the loads stay live.
 template <int NB>
@@ -1114,8 +1113,6 @@ __global__ __launch_bounds__(256) void gather_calibration_kernel(const float *ta
     const float s = (acc.x + acc.y) + (acc.z + acc.w);
     if (s == 12345.678f) out[0] = s;  // practically never: keeps the loads from being optimised away
 }
-
-#endif  // F2V_TEST_HOOKS
 
 // IPC preflight (f2v_diag_ipc_preflight): thread q stores a word into the mapped buffer and the mapped flag array of rank q
 struct PreflightArgs {
@@ -1148,10 +1145,21 @@ __global__ void xcc_probe_kernel(uint32_t *out) {
     if (threadIdx.x == 0) out[blockIdx.x] = id;
 }
 
-// On-box streaming ceiling: dst = src, 16 bytes per lane, grid-stride
-__global__ __launch_bounds__(256) void stream_copy_kernel(const float4 *src, float4 *dst, uint64_t n4) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n4; k += stride) dst[k] = src[k];
+// On-box streaming ceiling: dst = src, 16 bytes per lane.  Every workgroup copies ONE contiguous tile of
+// U x 256 x 16 bytes, all U loads in flight before the first store, non-temporal both ways (nothing is re-read): measured
+// 6.3-6.4 TB/s read + written on a 1-GiB copy, the guide's figure for the part (a grid-stride loop over 8192 workgroups,
+// round 1's kernel, reaches 4.9; tools/src/stream_copy_sweep.hip has the sweep).
+typedef float f32x4_copy_t __attribute__((ext_vector_type(4)));
+template <int U>
+__global__ __launch_bounds__(256) void stream_copy_kernel(const f32x4_copy_t *src, f32x4_copy_t *dst, uint64_t n4) {
+    const uint64_t base = (uint64_t)blockIdx.x * (U * 256u) + threadIdx.x;
+    f32x4_copy_t v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (base + (uint64_t)u * 256u < n4) v[u] = __builtin_nontemporal_load(src + base + (uint64_t)u * 256u);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (base + (uint64_t)u * 256u < n4) __builtin_nontemporal_store(v[u], dst + base + (uint64_t)u * 256u);
 }
 
 #ifdef F2V_TEST_HOOKS

@@ -64,9 +64,12 @@ int f2v_get_embeddings(f2v_handle h, float *x_out);
  * minibatch; every in-grid wait is bounded by "tree_timeout_ms", default 5000 -- a wait that gives up makes the
  * running f2v_train fail with F2V_ESTATE within an epoch or two, no unannounced sum is ever added, and the handle
  * falls back to 0), 0 = one launch per tree level; f2v_create selects 0 by itself when its dispatch probe does not
- * find 8 XCDs taking workgroups round robin ("xcc_count", "xcc_round_robin" answer what it saw); "quarter_wave": 0 selects the one-item-per-wavefront
+ * find 8 XCDs taking workgroups round robin ("xcc_count", "xcc_round_robin" answer what it saw); "piece_affinity" (default 1): a split row's pieces run on the XCD that owns
+ * the id range of their neighbours, so that each of the eight L2s caches its own eighth of the matrix (placement only:
+ * results do not change; ranks of a push exchange that share one GPU switch it off by themselves); "quarter_wave": 0 selects the one-item-per-wavefront
  * kernel for every D; "waves_per_block"; "rows_in_flight" (4|8); "use_graph" = 1 makes f2v_train replay a
- * captured hipGraph per epoch instead of launching eagerly (same results; measured no faster).
+ * captured hipGraph per epoch instead of launching eagerly (same results; measured no faster); "count_compulsory" = 1
+ * makes new launch plans count their compulsory bytes (f2v_stats.compulsory_bytes).
  * Sharded runs: "push_fused" (default 1: the step kernels push their rows themselves, 0: a kernel behind
  * them does), "push_timeout_ms".
  * "fast_rng" = 1 selects the NON-PARITY fast mode: initial embeddings and the option-7
@@ -191,6 +194,11 @@ typedef struct {
     double device_seconds;
     uint64_t hub_rows;
     uint64_t hub_chunks;
+    /* with "count_compulsory" = 1: sum over the launches of (distinct embedding rows read + rows written) * 4D + 4 bytes per
+     * neighbour id + 16 per work item -- the bytes a launch must move even if every re-read inside it hit a cache: the
+     * numerator of a roofline fraction that cannot exceed 1 (the SURVEY 8d figure above charges every neighbour row to
+     * HBM and does, on power-law graphs whose hub rows are cache hits). */
+    uint64_t compulsory_bytes;
 } f2v_stats;
 int f2v_get_stats(f2v_handle h, f2v_stats *out);
 
@@ -240,6 +248,9 @@ int f2v_sm_table(float *table_out /* 2048 */);
 int f2v_diag_ipc_preflight(int device, uint32_t rank, uint32_t world, const char *dir, uint64_t bytes, double timeout_s);
 /* On-box streaming-copy ceiling: read + written bytes per second (GB/s) of a 16-byte-per-lane copy of `bytes`, best of `reps`. */
 int f2v_diag_stream_copy(int device, uint64_t bytes, uint32_t reps, double *gbps_out);
+/* On-box random-row gather ceiling (GB/s, ids included): every 512-byte row of a `table_bytes` table fetched once per pass
+ * in random order with the step kernel's access pattern.  32 MiB: the Infinity Cache / L2 rate; 4 GiB: the HBM rate. */
+int f2v_diag_gather_rate(int device, uint64_t table_bytes, uint32_t reps, double *gbps_out);
 
 #ifdef __cplusplus
 }

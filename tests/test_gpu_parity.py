@@ -212,6 +212,28 @@ def test_combine_tree_give_up_is_safe_reported_at_once_and_recoverable(F):
         eng.close()
 
 
+@pytest.mark.parametrize("option,batch", [(5, 16384), (6, 4096)])
+def test_piece_affinity_is_placement_only(F, option, batch):
+    """ "piece_affinity" moves a split row's pieces to the XCD that owns their neighbours' id range (L2 locality): which
+    workgroup computes a piece changes, no bit of the result does -- and both equal the oracle on sampled rows."""
+    from force2vec_amd.graph import rmat_csr
+    rowptr, colids = rmat_csr(16, 16, seed=4)
+    res = []
+    for aff in (1, 0):
+        eng = F.Engine(rowptr, colids, 128)
+        assert eng.get_param("piece_affinity") == 1 and eng.get_param("shared_card") == 0
+        eng.set_param("piece_affinity", aff)
+        eng.set_param("hub_chunk", 16)
+        eng.srand(1)
+        eng.init_embeddings(0 if option == 5 else 1)
+        eng.train(option, 3, batch)
+        res.append(eng.get_embeddings())
+        eng.close()
+    assert np.array_equal(res[0], res[1]) and np.isfinite(res[0]).all()
+    want = O.train(option, rowptr, colids, 128, 3, batch, order=O.ORDER_TREE, chunk=16)
+    assert np.array_equal(res[0], want)
+
+
 def _csr(n, edges):
     r = np.array([e[0] for e in edges], dtype=np.int64)
     c = np.array([e[1] for e in edges], dtype=np.int64)

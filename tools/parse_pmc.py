@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 --pmc CSVs of tools/profile_traffic.sh into profiles/traffic.json:
-HBM bytes per launch of the dominant kernel, FETCH_SIZE corrected by the factor measured on the
-calibration kernel (known byte count, same access pattern), WRITE_SIZE taken as is."""
+"""Turns the rocprofv3 --pmc CSVs of tools/profile_traffic.sh into traffic.json: per launch of the dominant kernel, the
+bytes that left the XCDs' L2s (FETCH_SIZE corrected by the factor measured on the calibration kernel -- known byte count,
+same access pattern -- plus WRITE_SIZE), the L2 hit rate, the fabric read-request mix and average read latency next to
+the same figures of the calibration kernel reading from HBM and from the Infinity Cache, and the wave-level stall split."""
 import csv
 import glob
 import json
@@ -9,37 +10,75 @@ import os
 import sys
 
 
-def mean_counter(d, kernel_substr, counter):
-    vals = {}
+def counters(d, kernel_substr, skip_first=0):
+    """-> {counter: mean over dispatches}, number of dispatches; the first `skip_first` dispatches of the kernel are left out."""
+    per = {}
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == counter:
-                vals.setdefault(row["Dispatch_Id"], 0.0)
-                vals[row["Dispatch_Id"]] += float(row["Counter_Value"])
-    v = list(vals.values())
-    return (sum(v) / len(v), len(v)) if v else (None, 0)
+            if kernel_substr in row["Kernel_Name"]:
+                key = (row["Counter_Name"], int(row["Dispatch_Id"]))
+                per[key] = per.get(key, 0.0) + float(row["Counter_Value"])
+    names = sorted({k[0] for k in per})
+    out, nd = {}, 0
+    for nm in names:
+        ids = sorted(i for (c, i) in per if c == nm)[skip_first:]
+        if ids:
+            out[nm] = sum(per[(nm, i)] for i in ids) / len(ids)
+            nd = len(ids)
+    return out, nd
 
 
 def main():
-    prof, out, batch, scale, dim = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
-    cal_rows = 4 * 1024 * 1024
-    known = cal_rows * 512 + cal_rows * 4
-    f_cal, n1 = mean_counter(os.path.join(prof, "cal_FETCH_SIZE"), "gather_calibration_kernel", "FETCH_SIZE")
-    f_step, n2 = mean_counter(os.path.join(prof, "pmc_FETCH_SIZE"), "qstep_kernel", "FETCH_SIZE")
-    w_step, n3 = mean_counter(os.path.join(prof, "pmc_WRITE_SIZE"), "qstep_kernel", "WRITE_SIZE")
-    f_fin, _ = mean_counter(os.path.join(prof, "pmc_FETCH_SIZE"), "hub_finalize_kernel", "FETCH_SIZE")
-    w_fin, _ = mean_counter(os.path.join(prof, "pmc_WRITE_SIZE"), "hub_finalize_kernel", "WRITE_SIZE")
-    factor = known / (f_cal * 1024.0)
-    res = {"batch": batch, "scale": scale, "dim": dim,
-           "calibration": {"kernel": "gather_calibration_kernel<2>", "known_bytes_per_launch": known, "FETCH_SIZE_KiB": f_cal,
-                           "bytes_per_FETCH_SIZE_KiB": factor * 1024.0, "correction_factor": factor, "launches": n1},
-           "step_kernel": {"FETCH_SIZE_KiB": f_step, "WRITE_SIZE_KiB": w_step, "launches": n2},
-           "hub_finalize_kernel": {"FETCH_SIZE_KiB": f_fin, "WRITE_SIZE_KiB": w_fin},
-           "hbm_bytes_per_launch": f_step * 1024.0 * factor + w_step * 1024.0,
-           "note": "FETCH_SIZE x correction_factor (measured on the calibration kernel: same 16-lane dwordx4 row gathers, every byte "
-                   "fetched once from a 2 GiB table) + WRITE_SIZE (exact for 16-B/lane stores), KiB -> bytes; per step-kernel launch"}
+    prof, out = sys.argv[1], sys.argv[2]
+    batch, scale, dim = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+    option = int(sys.argv[6]) if len(sys.argv) > 6 else 5
+    K = "qstep_kernel"
+    step = {}
+    for name in ("fetch", "write", "l2", "ea_rd", "ea_wr", "sq"):
+        c, nd = counters(os.path.join(prof, "pmc_" + name), K)
+        step.update(c)
+        step["launches_" + name] = nd
+    bench_line = {}
+    try:
+        bench_line = json.loads([l for l in open(os.path.join(prof, "pmc_fetch.json")) if l.startswith("{")][-1])
+    except Exception:
+        pass
+    cal = {}
+    for where, rows in (("hbm", 4194304), ("mall", 393216)):
+        c = {}
+        for kind in ("fetch", "ea", "l2"):
+            cc, nd = counters(os.path.join(prof, "cal_%s_%s" % (where, kind)), "gather_calibration_kernel", skip_first=2)
+            c.update(cc)
+        c["known_bytes_per_launch"] = rows * 512 + rows * 4
+        if c.get("TCC_EA0_RDREQ_sum"):
+            c["avg_ea_read_latency_cycles"] = c["TCC_EA0_RDREQ_LEVEL_sum"] / c["TCC_EA0_RDREQ_sum"]
+        if c.get("TCC_HIT_sum") is not None and c.get("TCC_MISS_sum"):
+            c["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+        cal[where] = c
+    factor = cal["hbm"]["known_bytes_per_launch"] / (cal["hbm"]["FETCH_SIZE"] * 1024.0)
+    l2_miss = step["FETCH_SIZE"] * 1024.0 * factor + step["WRITE_SIZE"] * 1024.0
+    res = {"batch": batch, "scale": scale, "dim": dim, "option": option,
+           "hub_chunk": (bench_line.get("config") or {}).get("hub_chunk"), "kernel": (bench_line.get("roofline") or {}).get("kernel"),
+           "library": None,
+           "l2_miss_bytes_per_launch": l2_miss,
+           "l2_hit_rate": step["TCC_HIT_sum"] / (step["TCC_HIT_sum"] + step["TCC_MISS_sum"]) if step.get("TCC_MISS_sum") else None,
+           "avg_ea_read_latency_cycles": step["TCC_EA0_RDREQ_LEVEL_sum"] / step["TCC_EA0_RDREQ_sum"] if step.get("TCC_EA0_RDREQ_sum") else None,
+           "fetch_correction_factor": factor,
+           "step_kernel": step, "calibration": cal,
+           "note": "l2_miss_bytes_per_launch = FETCH_SIZE x fetch_correction_factor (measured on the calibration kernel: the same 16-lane dwordx4 row "
+                   "gathers, every byte fetched once from a 2-GiB table) + WRITE_SIZE (exact for 16-B/lane stores), KiB -> bytes, mean over the step "
+                   "kernel's launches.  These are requests of the L2s to the fabric: Infinity-Cache hits are included (MI355X_MICROARCH.md, HBM); "
+                   "rocprofv3 -L lists no counter beyond the TCC on this part, so HBM and Infinity Cache cannot be split by counters.  "
+                   "avg_ea_read_latency_cycles (TCC_EA0_RDREQ_LEVEL / TCC_EA0_RDREQ) next to calibration.hbm / calibration.mall shows which of the two the "
+                   "kernel's misses resemble."}
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from force2vec_amd import _lib
+        res["library"] = _lib.lib().f2v_version().decode()
+    except Exception:
+        pass
     json.dump(res, open(out, "w"), indent=1)
-    print(json.dumps(res))
+    print(json.dumps({k: v for k, v in res.items() if k not in ("step_kernel", "calibration", "note")}))
 
 
 if __name__ == "__main__":
