@@ -1459,10 +1459,13 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
     auto draw_epoch = [&](std::vector<uint32_t> &v, size_t off) {
         for (uint32_t b = 0; b < nb; b++) {
             uint32_t maxv = n - 1;
-            if (math == 7) {  // algorithms.cpp:1125
+            if (math == 7) {  // algorithms.cpp:1125 (option 10: :2124)
                 const uint64_t e = (uint64_t)(b + 1) * batch;
                 if (e < maxv) maxv = (uint32_t)e;
             }
+            // option 9's own rule (AlgoForce2VecNSRW_SREAL_D128_AVXZ): full minibatches draw from [0, (b+1)*BATCHSIZE)
+            // (algorithms.cpp:1700-1704; reaches vertex N-1 when the batch size divides N), the tail from [0, N-1) (:1939-1941)
+            if (option == 9 && b < n / batch) maxv = (b + 1) * batch;
             for (uint64_t s = 0; s < ndraw; s++) {
                 const uint32_t r = c->rng.index(maxv, 0);
                 if (s < stride) v[off + (size_t)b * stride + s] = r;

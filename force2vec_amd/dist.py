@@ -363,6 +363,8 @@ class ShardedTrainer:
             ids = np.zeros(nb * stride, dtype=np.uint32)
             for b in range(nb):
                 maxv = min((b + 1) * batch, n - 1) if math == 7 else n - 1  # algorithms.cpp:1125
+                if option == 9 and b < n // batch:
+                    maxv = (b + 1) * batch  # option 9's own range for full minibatches (algorithms.cpp:1700-1704)
                 keep = min(stride, ndraw)  # -bs 1 draws ns*BATCH ids of which rows+ns-1 are ever read
                 ids[b * stride: b * stride + keep] = e.draw_samples(maxv, ndraw, keep)
             return ids

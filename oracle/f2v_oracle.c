@@ -465,6 +465,12 @@ int orc_train(int option, int bs_mode, const uint32_t *rowptr, const uint32_t *c
               uint64_t nnz, uint32_t D, float *X, orc_rng *g, uint32_t iters, uint32_t batch,
               uint32_t ns, float lr, int order, uint32_t chunk, int do_init) {
     if (n < 2 || batch == 0) return -1;
+    /* The AVX512 twins (Test/Force2Vec.cpp:152-183) run the maths of options 5/6/7; what differs in their sources besides the
+     * arithmetic details (rcp14, FMA, 4 partial dot sums) is option 9's negative-sample range, kept here as `cli_option`. */
+    const int cli_option = option;
+    if (option == 8 || option == 11) option = 5;
+    else if (option == 9) option = 6;
+    else if (option == 10) option = 7;
     if (option == 7 && bs_mode) return -2;
     if (do_init) orc_init_embeddings(g, X, n, D, option == 5 ? 0 : 1);
     uint32_t nb = (n + batch - 1) / batch;
@@ -479,10 +485,13 @@ int orc_train(int option, int bs_mode, const uint32_t *rowptr, const uint32_t *c
             uint32_t lo = b * batch;
             uint32_t hi = lo + batch < n ? lo + batch : n;
             uint32_t maxv = n - 1;
-            if (option == 7) { /* algorithms.cpp:1125 */
+            if (option == 7) { /* algorithms.cpp:1125 (option 10: :2124) */
                 uint64_t e = (uint64_t)(b + 1) * batch;
                 if (e < maxv) maxv = (uint32_t)e;
             }
+            /* option 9 (AlgoForce2VecNSRW_SREAL_D128_AVXZ): full minibatches draw from [0, (b+1)*BATCHSIZE) -- algorithms.cpp:1700-1704,
+             * which reaches vertex N-1 when the batch size divides N -- the tail minibatch from [0, N-1) (:1939-1941) */
+            if (cli_option == 9 && b < n / batch) maxv = (b + 1) * batch;
             for (uint32_t s = 0; s < ndraw; s++) ids[s] = rand_index(g, maxv, 0);
             rc = orc_minibatch(option, bs_mode, rowptr, colids, n, D, X, lo, hi, lo, hi, ids, ns, lr,
                                walks, order, chunk);

@@ -10,6 +10,12 @@ option 6/7 goldens can be reproduced on hosts whose rcpps differs, and the first
 libc rand() after srand(1).
 
 Usage: python oracle/make_golden.py      (from the repo root, in the build container)
+       python oracle/make_golden.py --avx512-only   (only the "avx512_cases" / option-11 F1 sections, manifest updated in place)
+
+Options 8-11 (the AVX512 twins, oracle/_ref/Force2Vec_avx512): per case the md5 of the text and a sample of it -- the whole
+text for karate, every 8th row parsed to fp32 for cora -- against which the oracle (CPU test) and the HIP path (GPU test) are
+compared within a stated tolerance: these variants compute with rcp14 / FMA / four partial dot sums, so they are not
+bit-comparable with anything but themselves.
 """
 import ctypes
 import gzip
@@ -63,8 +69,59 @@ CASES = [
 ]
 
 
+# (graph, option, iters, batch, dim): options 8/11 on tail-free shapes (their tail minibatch has the sign defect of
+# algorithms.cpp:1585/:2810, which nothing here reproduces), options 9/10 also with a tail
+AVX_CASES = [
+    ("karate.mtx", 8, 1, 17, 128), ("karate.mtx", 8, 10, 17, 128), ("karate.mtx", 11, 10, 17, 128),
+    ("karate.mtx", 9, 10, 17, 128), ("karate.mtx", 9, 10, 16, 128), ("karate.mtx", 10, 5, 17, 128), ("karate.mtx", 10, 5, 16, 128),
+    ("cora.mtx", 8, 1, 677, 128), ("cora.mtx", 8, 10, 677, 128), ("cora.mtx", 11, 10, 677, 128), ("cora.mtx", 8, 100, 677, 128),
+    ("cora.mtx", 9, 10, 677, 128), ("cora.mtx", 9, 10, 256, 128), ("cora.mtx", 10, 5, 677, 128), ("cora.mtx", 10, 5, 256, 128),
+]
+
+
+def avx512_sections(manifest):
+    """manifest["avx512_cases"] and the reference-option-11 F1 table, from oracle/_ref/Force2Vec_avx512."""
+    cases = []
+    for g, option, iters, batch, dim in AVX_CASES:
+        mtx = os.path.join(REF_INPUT, g)
+        with tempfile.TemporaryDirectory() as td:
+            path, _ = O.run_reference(mtx, td, option, iters, batch, dim, threads=1, avx512=True)
+            txt = open(path, "rb").read()
+            name = "%s_opt%d_it%d_B%d_D%d_avx512" % (g.replace(".mtx", ""), option, iters, batch, dim)
+            entry = {"name": name, "graph": g, "option": option, "iters": iters, "batch": batch, "dim": dim, "ns": 5, "lr": 0.02,
+                     "md5": hashlib.md5(txt).hexdigest(), "embd_name": os.path.basename(path)}
+            X = O.read_embd(path)
+            stride = 1 if g == "karate.mtx" else 8
+            entry["row_stride"] = stride
+            entry["file"] = name + ".rows.f32.gz"
+            with gzip.GzipFile(os.path.join(GOLD, entry["file"]), "wb", mtime=0) as f:
+                f.write(np.ascontiguousarray(X[::stride], dtype="<f4").tobytes())
+            cases.append(entry)
+            print(name, entry["md5"])
+    manifest["avx512_cases"] = cases
+    manifest["avx512_reference_flags"] = manifest["reference_flags"] + " -mavx512f -mavx512dq -DAVX512=1"
+    # node-classification F1 of the reference's OWN option 11 at the CLI's tail-producing shape (cora, batch 256: 148 tail rows
+    # run the sign-flipped clean-up loop): the level the HIP path's option 11 must NOT fall to
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import f1_harness as H
+    labels = H.load_labels(os.path.join(REF_INPUT, "cora.nodes.labels"), 2708)
+    with tempfile.TemporaryDirectory() as td:
+        path, _ = O.run_reference(os.path.join(REF_INPUT, "cora.mtx"), td, 11, 1200, 256, 128, threads=1, avx512=True)
+        f1 = H.f1_scores(O.read_embd(path), labels)
+        manifest["f1_reference_cora_opt11_it1200_B256_D128"] = {"%.2f" % k: {"micro": v[0], "macro": v[1]} for k, v in f1.items()}
+        manifest["f1_reference_cora_opt11_it1200_B256_D128"]["md5"] = hashlib.md5(open(path, "rb").read()).hexdigest()
+    print(manifest["f1_reference_cora_opt11_it1200_B256_D128"])
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if "--avx512-only" in sys.argv:
+        with open(os.path.join(GOLD, "manifest.json")) as f:
+            manifest = json.load(f)
+        avx512_sections(manifest)
+        with open(os.path.join(GOLD, "manifest.json"), "w") as f:
+            json.dump(manifest, f, indent=1)
+        return
     manifest = {"generator": "oracle/make_golden.py", "reference_flags": "-g -fomit-frame-pointer -ffast-math -fopenmp -O3 -std=c++11 -DCPP",
                 "compiler": os.popen("g++ --version").readline().strip(), "cases": []}
     for g, option, iters, batch, dim, bs, keep in CASES:
@@ -106,6 +163,7 @@ def main():
     for _ in range(1000000):
         v = libc.rand()
     manifest["rand_1000000th"] = v
+    avx512_sections(manifest)
     with open(os.path.join(GOLD, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1)
 

@@ -395,7 +395,43 @@ def test_hipgraph_replay_equals_eager_launches(F, option, batch, iters):
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
 
 
-def test_options_8_to_11_alias_the_same_maths(F):
+def avx512_golden(case):
+    raw = gzip.open(os.path.join(GOLD, case["file"]), "rb").read()
+    return np.frombuffer(raw, dtype="<f4").reshape(-1, case["dim"])
+
+
+def avx512_tolerance(case):
+    """Max-abs tolerance against the reference's AVX512 outputs (oracle/_ref/Force2Vec_avx512, 6-digit text).  Those variants
+    compute d1 with rcp14 (relative error <= 2^-14 per force term), FMA and four partial dot sums, so options 8/11 sit
+    ~5e-6 from the scalar maths after 1-10 epochs and 1.6e-5 after 100 (measured with the oracle, tests/test_oracle_golden.py);
+    options 9/10 have no reciprocal in them: 1e-6, print resolution included."""
+    if case["option"] in (8, 11):
+        return 2e-5 if case["iters"] <= 10 else 5e-5
+    return 5e-6
+
+
+def test_options_8_to_11_match_the_reference_avx512_outputs(F, manifest):
+    """Options 8-11 against what the reference's own AVX512 build wrote for them (goldens by oracle/make_golden.py): 8 and
+    11 on tail-free shapes (their tail minibatch has a sign defect nothing here reproduces), 9 and 10 with and without a
+    tail -- option 9 keeps its own negative-sample range (algorithms.cpp:1700-1704).  Within the stated tolerance of the
+    reference, and bit-identical to the oracle's restatement of the same option."""
+    assert len(manifest["avx512_cases"]) >= 12
+    for case in manifest["avx512_cases"]:
+        rowptr, colids = F.read_mtx(golden_graph_path(case["graph"]))
+        a = F.algorithms((rowptr, colids), dim=case["dim"])
+        a.engine.set_param("hub_chunk", 64)
+        a.srand(1)
+        a._run(case["option"], 0, case["iters"], case["batch"], 5, 0.02, write=False)
+        got = a.nCoordinates
+        a.engine.close()
+        ref = avx512_golden(case)
+        err = float(np.abs(got[:: case["row_stride"]] - ref).max())
+        assert err < avx512_tolerance(case), (case["name"], err)
+        want = O.train(case["option"], rowptr, colids, case["dim"], case["iters"], case["batch"], order=O.ORDER_TREE, chunk=64)
+        assert np.array_equal(got, want), case["name"]
+
+
+def test_options_8_11_run_option_5_maths_and_10_option_7(F):
     rowptr, colids = F.read_mtx(golden_graph_path("karate.mtx"))
     res = {}
     for opt in (5, 8, 11, 6, 9, 7, 10):
@@ -404,8 +440,29 @@ def test_options_8_to_11_alias_the_same_maths(F):
         a._run(opt, 0, 3, 16, 5, 0.02, write=False)
         res[opt] = a.nCoordinates
         a.engine.close()
-    assert np.array_equal(res[5], res[8]) and np.array_equal(res[5], res[11])
-    assert np.array_equal(res[6], res[9]) and np.array_equal(res[7], res[10])
+    assert np.array_equal(res[5], res[8]) and np.array_equal(res[5], res[11]) and np.array_equal(res[7], res[10])
+    assert not np.array_equal(res[6], res[9])  # option 9 draws its negative samples from [0, (b+1)*BATCH) in full minibatches
+
+
+def test_option_11_f1_is_on_the_good_side_of_the_reference(F, manifest):
+    """Cora, batch 256 (148 tail rows), 1200 epochs, D = 128.  The reference's own option 11 scores ~5 points below its
+    option 5 there (sign-flipped attraction in the tail minibatch, algorithms.cpp:2810).  Option 11 here = option 5's maths
+    with hub rows load-balanced: its F1 must be level with the reference's OPTION 5 (+-0.5) and clearly above the
+    reference's option 11 -- the documented deviation is the good side of the defect."""
+    import f1_harness as H
+    rowptr, colids = F.read_mtx(golden_graph_path("cora.mtx"))
+    algo = F.algorithms((rowptr, colids), dim=128)
+    algo.srand(1)
+    algo._run(11, 0, 1200, 256, 5, 0.02, write=False)
+    labels = H.load_labels(os.path.join(GOLD, "cora.nodes.labels"), len(rowptr) - 1)
+    got = H.f1_scores(algo.nCoordinates, labels)
+    algo.engine.close()
+    ref5, ref11 = manifest["f1_reference_cora_opt5_it1200_B256_D128"], manifest["f1_reference_cora_opt11_it1200_B256_D128"]
+    for tf, (mic, mac) in got.items():
+        k = "%.2f" % tf
+        assert abs(mic - ref5[k]["micro"]) <= 0.5, (tf, mic, ref5[k]["micro"])
+        assert mic >= ref11[k]["micro"] + 3.0, (tf, mic, ref11[k]["micro"])
+        assert ref5[k]["micro"] - ref11[k]["micro"] >= 3.0
 
 
 def test_cli_drop_in(F, tmp_path):
