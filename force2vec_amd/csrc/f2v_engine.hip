@@ -51,6 +51,16 @@ struct Plan {
     uint64_t compulsory = 0;  // bytes this launch must move even with perfect caching inside the launch ("count_compulsory")
 };
 
+// One launch of qstep_chain_kernel: up to 64 consecutive minibatches (f2v_kernels.hip.h, "chained minibatches")
+struct ChainPlan {
+    size_t item_off = 0, fin_off = 0, wg_off = 0, bdesc_off = 0;
+    uint32_t n_wgs = 0, n_batches = 0, n_slots = 0, n_fin = 0;
+    uint32_t first_batch = 0;  // global minibatch index of its first minibatch
+    uint32_t lo = 0, hi = 0;   // rows covered
+    uint64_t nnz = 0, compulsory = 0;
+    uint32_t n_hubs = 0, n_chunks = 0;
+};
+
 // what a rank hands its peers (f2v_push_export): F2V_PUSH_EXPORT_BYTES bytes
 struct PushExport {
     hipIpcMemHandle_t x[2], flags;  // landing-buffer mode: x[0] is the landing buffer, x[1] unused
@@ -92,6 +102,16 @@ struct f2v_ctx {
     bool chunk_auto = true;  // f2v_train / "hub_chunk_for_batch" pick the chunk from the batch size
     bool use_quarter = true;  // sub-wave kernel when D is a multiple of 4 up to 256
     std::map<std::tuple<uint32_t, uint32_t, int>, Plan> plans;
+    // chained minibatches ("chain_batches"): one launch per group of minibatches of f2v_train
+    std::map<std::tuple<uint32_t, uint32_t, uint32_t>, ChainPlan> chains;  // (first minibatch, minibatches, batch size)
+    std::vector<WgDesc> h_wg;
+    std::vector<BatchDesc> h_bdesc;
+    WgDesc *d_wg = nullptr;
+    BatchDesc *d_bdesc = nullptr;
+    size_t d_wg_cap = 0, d_bdesc_cap = 0, d_wg_valid = 0, d_bdesc_valid = 0;
+    uint32_t *d_rowflag = nullptr;  // per row: sequence number of the chained launch that last wrote it
+    bool chain = true;            // "chain_batches"
+    uint32_t chain_max_batch = 512, chain_rows = 16384;  // measured on RMAT-20: chaining wins up to batch ~512 (tools/small_batch.py)
     std::vector<Item> h_items;
     std::vector<FinItem> h_hubs;
     Item *d_items = nullptr;
@@ -162,6 +182,10 @@ uint32_t auto_chunk(const f2v_ctx *c, uint32_t batch) {
 
 void drop_plans(f2v_ctx *c) {
     c->plans.clear();
+    c->chains.clear();
+    c->h_wg.clear();
+    c->h_bdesc.clear();
+    c->d_wg_valid = c->d_bdesc_valid = 0;
     c->max_slots = 0;
     c->h_items.clear();
     c->h_hubs.clear();
@@ -182,6 +206,28 @@ uint32_t items_per_block(const f2v_ctx *c) {
     const uint32_t w = subwave_width(c);
     const uint32_t per_wave = !w ? 1u : (w == 16 ? 16u : w == 32 ? 8u : 4u);
     return per_wave * (uint32_t)c->waves_per_block;
+}
+
+// Compulsory bytes of one minibatch: every DISTINCT embedding row it reads (its own rows and their neighbours) once, every
+// row it writes once, its neighbour ids and work items once -- what would still cross HBM if everything read twice inside
+// the minibatch came from a cache the second time.  (The ns sampled rows, the partial sums of split rows and rowptr are
+// left out: a lower bound.)
+uint64_t compulsory_bytes(f2v_ctx *c, uint32_t row_lo, uint32_t row_hi, bool walk, uint64_t nnz, uint64_t n_items) {
+    if (c->seen_stamp.size() != c->n) { c->seen_stamp.assign(c->n, 0u); c->stamp = 0; }
+    if (++c->stamp == 0) { std::fill(c->seen_stamp.begin(), c->seen_stamp.end(), 0u); c->stamp = 1; }
+    const uint32_t st = c->stamp;
+    uint32_t *seen = c->seen_stamp.data();
+    uint64_t distinct = 0;
+    const uint32_t *ids = walk ? nullptr : c->colids.data();
+    for (uint32_t i = row_lo; i < row_hi; i++) {
+        if (seen[i] != st) { seen[i] = st; distinct++; }
+        if (!ids) continue;  // walk samples change every epoch: only the rows themselves are counted
+        for (uint32_t k = c->rowptr[i]; k < c->rowptr[i + 1]; k++) {
+            const uint32_t j = ids[k];
+            if (seen[j] != st) { seen[j] = st; distinct++; }
+        }
+    }
+    return distinct * 4ull * c->D + (uint64_t)(row_hi - row_lo) * 4ull * c->D + nnz * 4ull + n_items * sizeof(Item);
 }
 
 // Work items of one launch (rows [row_lo,row_hi), CSR neighbours or walk samples): a whole row, or
@@ -346,29 +392,132 @@ const Plan &plan_for(f2v_ctx *c, uint32_t row_lo, uint32_t row_hi, bool walk) {
         slots++;
     }
     p.n_slots = slots;
-    if (c->count_compulsory) {
-        // Compulsory bytes of this launch: every DISTINCT embedding row it reads (its own rows and their neighbours) once,
-        // every row it writes once, its neighbour ids and work items once -- what would still cross HBM if everything
-        // read twice inside the launch came from a cache the second time.  (The ns sampled rows, the partial sums of split
-        // rows and rowptr are left out: a lower bound.)
-        if (c->seen_stamp.size() != c->n) { c->seen_stamp.assign(c->n, 0u); c->stamp = 0; }
-        if (++c->stamp == 0) { std::fill(c->seen_stamp.begin(), c->seen_stamp.end(), 0u); c->stamp = 1; }
-        const uint32_t st = c->stamp;
-        uint32_t *seen = c->seen_stamp.data();
-        uint64_t distinct = 0;
-        const uint32_t *ids = walk ? nullptr : c->colids.data();
-        for (uint32_t i = row_lo; i < row_hi; i++) {
-            if (seen[i] != st) { seen[i] = st; distinct++; }
-            if (!ids) continue;  // walk samples change every epoch: only the rows themselves are counted
-            for (uint32_t k = c->rowptr[i]; k < c->rowptr[i + 1]; k++) {
-                const uint32_t j = ids[k];
-                if (seen[j] != st) { seen[j] = st; distinct++; }
-            }
-        }
-        p.compulsory = distinct * 4ull * c->D + (uint64_t)(row_hi - row_lo) * 4ull * c->D + p.nnz * 4ull + (uint64_t)p.n_items * sizeof(Item);
-    }
+    if (c->count_compulsory) p.compulsory = compulsory_bytes(c, row_lo, row_hi, walk, p.nnz, p.n_items);
     c->max_slots = std::max<size_t>(c->max_slots, slots);
     return c->plans.emplace(key, p).first->second;
+}
+
+// Minibatches per chained launch ("chain_rows" rows per launch, at most 4096 minibatches)
+uint32_t chain_len(const f2v_ctx *c, uint32_t batch) {
+    const uint64_t k = (uint64_t)c->chain_rows / std::max(batch, 1u);
+    return (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(k, 1));
+}
+
+bool chain_usable(const f2v_ctx *c, int math, uint32_t batch, int bs_mode, bool sharded) {
+    const uint32_t nb = (uint32_t)(((uint64_t)c->n + batch - 1) / batch);
+    return c->chain && !sharded && !bs_mode && math != 7 && c->merge_fin && c->xcc_round_robin && !c->capturing && !c->use_graph &&
+           subwave_width(c) != 0 && c->D % 32u == 0u && batch <= c->chain_max_batch && nb >= 2 && chain_len(c, batch) >= 2;
+}
+
+// The work of minibatches [b0, b0+K) of batch size `batch` as ONE launch: per minibatch its items (rows whose neighbours all
+// lie outside the launch's earlier minibatches first: their workgroups never wait), then its combine-tree nodes; a
+// descriptor per workgroup with the minibatches it has to wait for.  Same pieces, same fan-in, same slots-in-chunk-order as
+// plan_for: the summation order -- and with it every bit of the result -- does not depend on how minibatches are launched.
+const ChainPlan &chain_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t batch) {
+    const auto key = std::make_tuple(b0, K, batch);
+    auto itp = c->chains.find(key);
+    if (itp != c->chains.end()) return itp->second;
+    const uint32_t ipb = items_per_block(c), npb = (uint32_t)c->waves_per_block;
+    ChainPlan p;
+    p.first_batch = b0;
+    p.n_batches = K;
+    p.item_off = c->h_items.size();
+    p.fin_off = c->h_hubs.size();
+    p.wg_off = c->h_wg.size();
+    p.bdesc_off = c->h_bdesc.size();
+    p.lo = (uint32_t)std::min<uint64_t>((uint64_t)b0 * batch, c->n);
+    uint32_t slots = 0;
+    struct DI { Item it; uint64_t dep; };
+    std::vector<DI> items;
+    struct Node { uint32_t row, in_slot, n; };
+    std::vector<Node> cur, nxt;
+    for (uint32_t k = 0; k < K; k++) {
+        const uint32_t lo = (uint32_t)std::min<uint64_t>((uint64_t)(b0 + k) * batch, c->n);
+        const uint32_t hi = (uint32_t)std::min<uint64_t>((uint64_t)lo + batch, c->n);
+        p.hi = hi;
+        items.clear();
+        cur.clear();
+        uint64_t nnz = 0;
+        auto dep_of = [&](uint32_t from, uint32_t to) -> uint64_t {  // 1 + the LAST row of this launch's earlier minibatches among the neighbours [from,to): 0 = independent
+            uint64_t m = 0;
+            for (uint32_t e = from; e < to; e++) {
+                const uint32_t j = c->colids[e];
+                if (j >= p.lo && j < lo) m = std::max<uint64_t>(m, (uint64_t)(j - p.lo) + 1);
+            }
+            return m;
+        };
+        for (uint32_t i = lo; i < hi; i++) {
+            const uint32_t rp = c->rowptr[i], deg = c->rowptr[i + 1] - rp;
+            nnz += deg;
+            if (c->chunk != 0 && deg > c->chunk) {
+                const uint32_t nc = (deg + c->chunk - 1) / c->chunk;
+                for (uint32_t q = 0; q < nc; q++) {
+                    const uint32_t b = q * c->chunk, e = std::min(deg, b + c->chunk);
+                    items.push_back(DI{Item{i, rp + b, e - b, kItemPartial | (q == 0 ? kItemFirst : 0u) | (q == nc - 1 ? kItemLast : 0u) | (slots + q)}, dep_of(rp + b, rp + e)});
+                }
+                cur.push_back(Node{i, slots, nc});
+                slots += nc;
+                p.n_hubs++;
+                p.n_chunks += nc;
+            } else {
+                items.push_back(DI{Item{i, rp, deg, kItemFirst | kItemLast}, dep_of(rp, rp + deg)});
+            }
+        }
+        // independent items first (longest first), then the dependent ones, those that wait for the oldest rows first
+        std::stable_sort(items.begin(), items.end(), [](const DI &x, const DI &y) {
+            if ((x.dep != 0) != (y.dep != 0)) return x.dep == 0;
+            if (x.dep != y.dep && x.dep != 0) return x.dep < y.dep;
+            return x.it.cnt > y.it.cnt;
+        });
+        if (items.size() % ipb != 0) {  // inert fillers: empty pieces whose (zero) sum goes to a slot no node reads
+            const Item pad{lo, 0, 0, kItemPartial | slots};
+            slots++;
+            while (items.size() % ipb != 0) items.push_back(DI{pad, 0});
+        }
+        BatchDesc bd{};
+        bd.lo = lo;
+        bd.item_off = (uint32_t)(c->h_items.size() - p.item_off);
+        bd.n_items = (uint32_t)items.size();
+        bd.step_blocks = bd.n_items / ipb;
+        bd.fin_off = (uint32_t)(c->h_hubs.size() - p.fin_off);
+        bd.index = b0 + k;
+        for (uint32_t w = 0; w < bd.step_blocks; w++) c->h_wg.push_back(WgDesc{k, w});
+        for (const DI &d : items) c->h_items.push_back(d.it);
+        // the combine trees of this minibatch's split rows, level by level (fan-in groups in chunk order, as plan_for)
+        uint32_t fin_n = 0;
+        for (int level = 0; !cur.empty(); level++) {
+            nxt.clear();
+            for (const Node &nd : cur) {
+                const uint32_t G = (level == kMaxFinLevels - 1 || c->fanin < 2) ? nd.n : c->fanin;
+                const uint32_t nout = (nd.n + G - 1) / G;
+                if (nout == 1) {
+                    c->h_hubs.push_back(FinItem{nd.in_slot, nd.n, kFinToStage, nd.row});
+                    fin_n++;
+                } else {
+                    for (uint32_t o = 0; o < nout; o++) {
+                        c->h_hubs.push_back(FinItem{nd.in_slot + o * G, std::min(G, nd.n - o * G), slots + o, nd.row});
+                        fin_n++;
+                    }
+                    nxt.push_back(Node{nd.row, slots, nout});
+                    slots += nout;
+                }
+            }
+            cur.swap(nxt);
+        }
+        while (fin_n % npb != 0) { c->h_hubs.push_back(FinItem{0, 0, kFinToStage, 0}); fin_n++; }
+        bd.fin_n = fin_n;
+        const uint32_t node_blocks = fin_n / npb;
+        for (uint32_t w = 0; w < node_blocks; w++) c->h_wg.push_back(WgDesc{k, bd.step_blocks + w});
+        bd.n_wgs = bd.step_blocks + node_blocks;
+        c->h_bdesc.push_back(bd);
+        p.n_wgs += bd.n_wgs;
+        p.n_fin += fin_n;
+        p.nnz += nnz;
+        if (c->count_compulsory) p.compulsory += compulsory_bytes(c, lo, hi, false, nnz, bd.n_items);
+    }
+    p.n_slots = slots;
+    c->max_slots = std::max<size_t>(c->max_slots, slots);
+    return c->chains.emplace(key, p).first->second;
 }
 
 // Make every plan built so far resident in HBM (and the partial-sum buffer large enough).
@@ -376,8 +525,30 @@ int upload_plans(f2v_ctx *c) {
     const size_t need_slots = c->max_slots;
     const bool grow_items = c->h_items.size() > c->d_items_cap, grow_hubs = c->h_hubs.size() > c->d_hubs_cap;
     const bool grow_slots = need_slots > c->partial_slots;
-    if (c->h_items.size() == c->d_items_valid && c->h_hubs.size() == c->d_hubs_valid && !grow_slots) return F2V_OK;  // O(1) steady state
+    if (c->h_items.size() == c->d_items_valid && c->h_hubs.size() == c->d_hubs_valid && c->h_wg.size() == c->d_wg_valid &&
+        c->h_bdesc.size() == c->d_bdesc_valid && !grow_slots)
+        return F2V_OK;  // O(1) steady state
     HIPC(hipStreamSynchronize(c->stream));  // launches in flight read these buffers
+    if (c->h_wg.size() > c->d_wg_cap) {
+        if (c->d_wg) (void)hipFree(c->d_wg);
+        c->d_wg = nullptr;
+        c->d_wg_cap = std::max<size_t>(c->h_wg.size() * 3 / 2, 1024);
+        HIPC(hipMalloc((void **)&c->d_wg, c->d_wg_cap * sizeof(WgDesc)));
+        c->d_wg_valid = 0;
+    }
+    if (c->h_bdesc.size() > c->d_bdesc_cap) {
+        if (c->d_bdesc) (void)hipFree(c->d_bdesc);
+        c->d_bdesc = nullptr;
+        c->d_bdesc_cap = std::max<size_t>(c->h_bdesc.size() * 3 / 2, 256);
+        HIPC(hipMalloc((void **)&c->d_bdesc, c->d_bdesc_cap * sizeof(BatchDesc)));
+        c->d_bdesc_valid = 0;
+    }
+    if (c->h_wg.size() > c->d_wg_valid)
+        HIPC(hipMemcpy(c->d_wg + c->d_wg_valid, c->h_wg.data() + c->d_wg_valid, (c->h_wg.size() - c->d_wg_valid) * sizeof(WgDesc), hipMemcpyHostToDevice));
+    if (c->h_bdesc.size() > c->d_bdesc_valid)
+        HIPC(hipMemcpy(c->d_bdesc + c->d_bdesc_valid, c->h_bdesc.data() + c->d_bdesc_valid, (c->h_bdesc.size() - c->d_bdesc_valid) * sizeof(BatchDesc), hipMemcpyHostToDevice));
+    c->d_wg_valid = c->h_wg.size();
+    c->d_bdesc_valid = c->h_bdesc.size();
     if (grow_items) {
         if (c->d_items) (void)hipFree(c->d_items);
         c->d_items = nullptr;
@@ -478,7 +649,7 @@ int kernel_gave_up(f2v_ctx *c, const char *where, const uint32_t *e) {
     (void)hipStreamSynchronize(c->stream);
     (void)hipMemsetAsync(c->d_kerr, 0, 64, c->stream);
     (void)hipStreamSynchronize(c->stream);
-    c->merge_fin = false;
+    c->merge_fin = false;  // (chained minibatches need it: off with it)
     c->pending = false;
     c->upd_lo = c->upd_hi = 0;
     c->have_x = false;
@@ -668,6 +839,73 @@ int launch_step(f2v_ctx *c, int math, uint32_t batch_lo, uint32_t batch_hi, uint
     c->stats.rows += rows;
     c->stats.nnz += plan.nnz;
     c->stats.algorithmic_bytes += plan.nnz * (4ull * c->D + 4) + rows * (8ull * c->D + 4) + (uint64_t)ns * (4ull * c->D + 4);
+    c->stats.compulsory_bytes += plan.compulsory;
+    return F2V_OK;
+}
+
+// One chained launch: minibatches [plan.first_batch, +plan.n_batches) of an epoch whose sample ids (ids_stride per minibatch)
+// lie at d_ids_epoch.
+int launch_chain(f2v_ctx *c, int math, const ChainPlan &plan, const uint32_t *d_ids_epoch, uint32_t ids_stride, uint32_t ns, float lr) {
+    int rc;
+    if (c->upd_hi != c->upd_lo && plan.lo != c->upd_hi) {
+        if ((rc = flush_pending(c)) != F2V_OK) return rc;
+    }
+    ChainArgs ca{};
+    StepArgs &a = ca.base;
+    a.X = c->d_X[c->cur];
+    a.Xn = c->d_X[c->cur ^ 1];
+    a.rowptr = c->d_rowptr;
+    a.nbr_ids = c->d_colids;
+    a.partials = c->d_partials;
+    a.items = c->d_items + plan.item_off;
+    a.sm_table = c->d_table;
+    a.D = c->D;
+    a.upd_lo = (c->upd_hi == c->upd_lo) ? plan.lo : c->upd_lo;
+    a.ns = ns;
+    a.bs_mode = 0u;
+    a.lr = lr;
+    a.fin_items = c->d_hubs + plan.fin_off;
+    a.ready = c->d_ready;
+    a.err = c->d_kerr;
+    a.timeout_ticks = tree_timeout_ticks(c);
+    a.seq = ++c->launch_seq;
+    if (a.seq == 0) a.seq = ++c->launch_seq;
+#ifdef F2V_TEST_HOOKS
+    a.test_withhold_slot = c->test_withhold_slot;
+#endif
+    a.rowflag = c->d_rowflag;
+    a.chain_lo = plan.lo;
+    ca.wg = c->d_wg + plan.wg_off;
+    ca.batch = c->d_bdesc + plan.bdesc_off;
+    ca.ids = d_ids_epoch;
+    ca.ids_stride = ids_stride;
+    const uint32_t width = subwave_width(c), wpb = (uint32_t)c->waves_per_block;
+    const bool full = width == c->D;
+    const int o = (math == 5) ? 5 : 6;
+#define F2V_C2(OPT, LPI, NB, U, FULL) hipLaunchKernelGGL((qstep_chain_kernel<OPT, LPI, NB, U, FULL>), dim3(plan.n_wgs), dim3(64 * wpb), 0, c->stream, ca)
+#define F2V_C(OPT, LPI, NB, U) do { if (full) F2V_C2(OPT, LPI, NB, U, true); else F2V_C2(OPT, LPI, NB, U, false); } while (0)
+    switch (width) {
+        case 32: if (o == 5) F2V_C(5, 8, 1, 8); else F2V_C(6, 8, 1, 8); break;
+        case 64: if (o == 5) F2V_C(5, 16, 1, 8); else F2V_C(6, 16, 1, 8); break;
+        // 8 rows in flight per item at D = 128 too: a chained launch is bound by the latency of the dependent items, not by
+        // occupancy (batch 256: 29.6 ms per epoch against 30.3 with 4)
+        case 128: if (o == 5) F2V_C(5, 16, 2, 8); else F2V_C(6, 16, 2, 8); break;
+        default: if (o == 5) F2V_C(5, 16, 4, 4); else F2V_C(6, 16, 4, 4); break;
+    }
+#undef F2V_C
+#undef F2V_C2
+    HIPC(hipGetLastError());
+    if (c->upd_hi == c->upd_lo) c->upd_lo = plan.lo;
+    c->upd_hi = plan.hi;
+    c->pending = true;
+    c->p_lo = (uint32_t)c->h_bdesc[plan.bdesc_off + plan.n_batches - 1].lo;
+    c->p_hi = plan.hi;
+    c->stats.hub_rows += plan.n_hubs;
+    c->stats.hub_chunks += plan.n_chunks;
+    c->stats.step_launches += 1;
+    c->stats.rows += plan.hi - plan.lo;
+    c->stats.nnz += plan.nnz;
+    c->stats.algorithmic_bytes += plan.nnz * (4ull * c->D + 4) + (uint64_t)(plan.hi - plan.lo) * (8ull * c->D + 4) + (uint64_t)plan.n_batches * ns * (4ull * c->D + 4);
     c->stats.compulsory_bytes += plan.compulsory;
     return F2V_OK;
 }
@@ -955,7 +1193,7 @@ int f2v_destroy(f2v_handle c) {
     (void)hipSetDevice(c->device);
     (void)push_detach(c);
     void *ptrs[] = {c->d_rowptr, c->d_colids, c->d_walks, c->d_ids, c->d_X[0], c->d_X[1],
-                    c->d_partials, c->d_table, c->d_items, c->d_hubs, c->d_ready, c->d_kerr, c->push.flags, c->push.d_err, c->push.d_masks, c->push.d_patch, c->push.landing_buf};
+                    c->d_partials, c->d_table, c->d_items, c->d_hubs, c->d_ready, c->d_kerr, c->d_wg, c->d_bdesc, c->d_rowflag, c->push.flags, c->push.d_err, c->push.d_masks, c->push.d_patch, c->push.landing_buf};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->h_kerr) (void)hipHostFree(c->h_kerr);
@@ -1151,6 +1389,25 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
         c->merge_fin = value != 0;
         return F2V_OK;
     }
+    if (!strcmp(name, "chain_batches")) {
+        c->chain = value != 0;
+        return F2V_OK;
+    }
+    if (!strcmp(name, "chain_max_batch")) {
+        if (value < 0 || value > 0xFFFFFFFFll) return fail(F2V_EINVAL, "chain_max_batch out of range");
+        c->chain_max_batch = (uint32_t)value;
+        return F2V_OK;
+    }
+    if (!strcmp(name, "chain_rows")) {  // rows one chained launch covers
+        if (value < 2 || value > 0x7FFFFFFFll) return fail(F2V_EINVAL, "chain_rows out of range");
+        HIPC(hipSetDevice(c->device));
+        int rc = flush_pending(c);
+        if (rc != F2V_OK) return rc;
+        HIPC(hipStreamSynchronize(c->stream));
+        c->chain_rows = (uint32_t)value;
+        drop_plans(c);
+        return F2V_OK;
+    }
     if (!strcmp(name, "tree_timeout_ms")) {
         if (value < 1 || value > 600000) return fail(F2V_EINVAL, "tree_timeout_ms must be 1..600000");
         c->tree_timeout_ms = value;
@@ -1196,6 +1453,9 @@ int f2v_get_param(f2v_handle c, const char *name, int64_t *out) {
     if (!strcmp(name, "push_fused")) { *out = c->push.fused ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "merge_finalize")) { *out = c->merge_fin ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "tree_timeout_ms")) { *out = c->tree_timeout_ms; return F2V_OK; }
+    if (!strcmp(name, "chain_batches")) { *out = c->chain ? 1 : 0; return F2V_OK; }
+    if (!strcmp(name, "chain_max_batch")) { *out = c->chain_max_batch; return F2V_OK; }
+    if (!strcmp(name, "chain_rows")) { *out = c->chain_rows; return F2V_OK; }
     if (!strcmp(name, "xcc_count")) { *out = c->xcc_count; return F2V_OK; }
     if (!strcmp(name, "xcc_round_robin")) { *out = c->xcc_round_robin ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "push_landing")) { *out = (c->push.attached || c->push.exported) ? (c->push.landing ? 1 : 0) : (c->push.force_landing ? 1 : 0); return F2V_OK; }
@@ -1443,15 +1703,22 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
             drop_plans(c);
         }
     }
-    for (uint32_t b = 0; b < nb; b++) {  // all launch plans up-front: one upload, no syncs inside the timed loop
-        uint32_t lo = b * batch, hi = (uint32_t)std::min<uint64_t>((uint64_t)b * batch + batch, n);
-        if (sharded) shard_of(c, math == 7, lo, hi, c->push.rank, c->push.world, &lo, &hi);
-        (void)plan_for(c, lo, hi, math == 7);
-    }
-    if ((rc = upload_plans(c)) != F2V_OK) return rc;
     // Sample ids do not depend on the embeddings: options 5/6 pre-draw every epoch's ids (as long
     // as that stays below 1 GiB); option 7 interleaves walk generation, so it goes epoch by epoch.
     const bool all_upfront = (math != 7 || c->fast_rng) && (per_epoch * iters * 4ull <= (1ull << 30));
+    // small minibatches: groups of them in one launch (chain_plan_for), ordered by data dependencies instead of launch boundaries
+    const bool chained = all_upfront && iters > 0 && chain_usable(c, math, batch, bs_mode, sharded);
+    const uint32_t K = chained ? chain_len(c, batch) : 1;
+    if (chained) {
+        for (uint32_t b0 = 0; b0 < nb; b0 += K) (void)chain_plan_for(c, b0, std::min(K, nb - b0), batch);
+    } else {
+        for (uint32_t b = 0; b < nb; b++) {  // all launch plans up-front: one upload, no syncs inside the timed loop
+            uint32_t lo = b * batch, hi = (uint32_t)std::min<uint64_t>((uint64_t)b * batch + batch, n);
+            if (sharded) shard_of(c, math == 7, lo, hi, c->push.rank, c->push.world, &lo, &hi);
+            (void)plan_for(c, lo, hi, math == 7);
+        }
+    }
+    if ((rc = upload_plans(c)) != F2V_OK) return rc;
     const uint64_t dev_ids = std::max<uint64_t>(all_upfront ? per_epoch * std::max(iters, 1u) : per_epoch, 64);
     if ((rc = reserve_ids(c, dev_ids)) != F2V_OK) return rc;
     c->ids_valid = 0;
@@ -1476,6 +1743,11 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
         ids.assign(per_epoch * iters, 0u);
         for (uint32_t it = 0; it < iters; it++) draw_epoch(ids, (size_t)it * per_epoch);
         if (!ids.empty()) HIPC(hipMemcpy(c->d_ids, ids.data(), ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (chained && !c->d_rowflag) {
+            HIPC(hipMalloc((void **)&c->d_rowflag, (size_t)c->n * sizeof(uint32_t)));
+            HIPC(hipMemsetAsync(c->d_rowflag, 0, (size_t)c->n * sizeof(uint32_t), c->stream));  // 0 is no launch's sequence number
+            HIPC(hipStreamSynchronize(c->stream));
+        }
     } else {
         ids.assign(per_epoch, 0u);
     }
@@ -1574,7 +1846,14 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
             HIPC(hipStreamSynchronize(c->stream));
             HIPC(hipMemcpy(c->d_ids, ids.data(), ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         }
-        for (uint32_t b = 0; b < nb; b++) {
+        if (chained) {
+            for (uint32_t b0 = 0; b0 < nb; b0 += K) {
+                const ChainPlan plan = chain_plan_for(c, b0, std::min(K, nb - b0), batch);
+                if ((rc = upload_plans(c)) != F2V_OK) return rc;  // O(1) unless the plan cache was dropped meanwhile
+                if ((rc = launch_chain(c, math, plan, d_epoch_ids, (uint32_t)stride, ns, lr)) != F2V_OK) return rc;
+            }
+        }
+        for (uint32_t b = 0; b < nb && !chained; b++) {
             const uint32_t lo = b * batch;
             const uint32_t hi = (uint32_t)std::min<uint64_t>((uint64_t)lo + batch, n);
             uint32_t my_lo = lo, my_hi = hi;

@@ -104,6 +104,10 @@ struct StepArgs {
     uint32_t *ready;
     uint32_t *err;
     unsigned long long timeout_ticks;
+    // chained minibatches (qstep_chain_kernel): rows [chain_lo, chain_lo + chain_rows) are written by EARLIER minibatches of
+    // this very launch; a reader waits until rowflag[row] == seq before it loads one of them
+    uint32_t *rowflag;
+    uint32_t chain_lo, chain_rows;
 #ifdef F2V_TEST_HOOKS
     uint32_t test_withhold_slot;      // f2v_test_withhold_flag: the piece with this partial slot never announces (kNoSlot: none)
 #endif
@@ -461,6 +465,7 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
 // pieces announce their partial sums the same way, and a minibatch is ONE launch.
 struct FinalizeTreeArgs {
     FinalizeArgs f;           // items: all levels, lowest first; n_items: all of them
+    uint32_t *rowflag;        // chained minibatches: per row, the launch that last wrote it
     uint32_t *ready;          // per partial slot: sequence number of the launch that last produced it
     uint32_t *err;
     unsigned long long timeout_ticks;
@@ -541,8 +546,9 @@ __device__ __forceinline__ void add_partials(const float *p, uint32_t n, uint32_
     }
 }
 
-// one node of the trees: wave `w` of the nodes' part of a grid
-template <int OPT, int VEC, bool EXACT>
+// one node of the trees: wave `w` of the nodes' part of a grid.  ROW_THROUGH: the row's new embedding is written through at
+// agent scope too (chained minibatches: a later minibatch of the SAME launch reads it, possibly on another XCD).
+template <int OPT, int VEC, bool EXACT, bool ROW_THROUGH = false>
 __device__ __forceinline__ void finalize_tree_node(const FinalizeTreeArgs &a, uint32_t w, uint32_t lane) {
     const FinalizeArgs &f = a.f;
     if (w >= f.n_items) return;
@@ -590,7 +596,13 @@ __device__ __forceinline__ void finalize_tree_node(const FinalizeTreeArgs &a, ui
 #pragma unroll
             for (int v = 0; v < VEC; ++v) Y[v] = xi[v] + Y[v];
         }
-        store_row<VEC, EXACT>(f.Xn + (size_t)h.row * D, lane, D, Y);
+        if constexpr (ROW_THROUGH) {
+            store_row_agent<VEC, EXACT>(f.Xn + (size_t)h.row * D, lane, D, Y);
+            __builtin_amdgcn_s_waitcnt(0);  // the row is in memory before it is announced
+            if (lane == 0) __hip_atomic_store(a.rowflag + h.row, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            store_row<VEC, EXACT>(f.Xn + (size_t)h.row * D, lane, D, Y);
+        }
         if (f.push.world > 1u) {
             push_row<VEC, EXACT>(f.push, h.row, lane, D, Y);
             __builtin_amdgcn_s_waitcnt(0);
@@ -697,6 +709,35 @@ __device__ __forceinline__ void pair_update_q(const float (&xi)[NB][4], const fl
     }
 }
 
+// Chained minibatches: row j is written by an earlier minibatch of this launch -- wait until it has been announced
+// (rowflag[j] == seq, stored by its writer after the written-through row was acknowledged).  -> true: gave up (time-out, or
+// the launch is lost already); the caller then stores nothing.
+__device__ __noinline__ bool wait_row_slow(const StepArgs &a, uint32_t j) {
+    const uint32_t *f = a.rowflag + j;
+    const unsigned long long t0 = wall_clock64();
+    for (uint32_t spins = 1;; ++spins) {
+        __builtin_amdgcn_s_sleep(1);
+        if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.seq) return false;
+        if ((spins & 15u) != 0u) continue;
+        if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return true;
+        if (wall_clock64() - t0 > a.timeout_ticks) {
+            // err[0] code 3, [1] how many waits timed out, [2..7] the first: waiting workgroup, row, flag seen, seq, grid, minibatch's first row
+            if (__hip_atomic_fetch_add(a.err + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                a.err[2] = blockIdx.x; a.err[3] = j; a.err[4] = *f; a.err[5] = a.seq; a.err[6] = gridDim.x; a.err[7] = a.batch_lo;
+            }
+            __hip_atomic_store(a.err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return true;
+        }
+    }
+}
+
+__device__ __forceinline__ bool wait_row(const StepArgs &a, uint32_t j) {
+    bool bad = false;
+    if (__hip_atomic_load(a.rowflag + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.seq) bad = wait_row_slow(a, j);
+    asm volatile("" ::: "memory");  // the row's loads stay behind the poll
+    return bad;
+}
+
 __device__ __forceinline__ const float *row_src(const StepArgs &a, uint32_t j, uint32_t D) {
     return ((j - a.upd_lo) < a.upd_rows ? a.Xn : a.X) + (size_t)j * D;
 }
@@ -706,9 +747,9 @@ __device__ __forceinline__ const float *row_src(const StepArgs &a, uint32_t j, u
 // fetched one group ahead.
 // FULL: D == 4*LPI*NB.  Otherwise D is any smaller multiple of 4 (rows stay 16-byte aligned): lane t's block b is live
 // iff 4*LPI*b + 4t < D, dead pieces read as zero -- the zero padding of the canonical tree -- and are never stored.
-template <int OPT, int LPI, int NB, bool NEG, int U, bool FULL>
+template <int OPT, int LPI, int NB, bool NEG, int U, bool FULL, bool CHAIN>
 __device__ __forceinline__ void qprocess(const StepArgs &a, const uint32_t *ids, uint32_t cnt, uint32_t maxcnt, uint32_t t, uint32_t D,
-                                         const float (&xi)[NB][4], float (&Y)[NB][4], double c0, const float *table) {
+                                         const float (&xi)[NB][4], float (&Y)[NB][4], double c0, const float *table, bool &bad) {
     uint32_t j[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) j[u] = ((uint32_t)u < cnt) ? ids[u] : 0u;
@@ -717,6 +758,9 @@ __device__ __forceinline__ void qprocess(const StepArgs &a, const uint32_t *ids,
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (g + u < cnt) {
+                if constexpr (CHAIN) {
+                    if ((j[u] - a.chain_lo) < a.chain_rows) bad = wait_row(a, j[u]) || bad;
+                }
                 const float *src = row_src(a, j[u], D) + t * 4;
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
@@ -746,26 +790,29 @@ __device__ __forceinline__ uint32_t wave_max_of_items(uint32_t v) {
     return m;
 }
 
-template <int OPT, int LPI, int NB, int U, bool PUSH = false, bool FULL = true>
-__global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
+// The body of one workgroup: `blk` is its index in the minibatch's own grid (step items first, then tree nodes).
+// CHAIN: the minibatch is one of several in this launch (qstep_chain_kernel): finished rows are written through at agent
+// scope, because a later minibatch of the same launch may read them on another XCD.
+template <int OPT, int LPI, int NB, int U, bool PUSH, bool FULL, bool CHAIN>
+__device__ __forceinline__ void qstep_body(const StepArgs &a, const uint32_t blk) {
     constexpr uint32_t DP = 4u * LPI * NB, IPW = 64u / LPI;  // padded dims (the tree's width); items per wavefront
     const uint32_t D = FULL ? DP : a.D;                       // live dims = row stride
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t t = lane & (LPI - 1u), q = lane / LPI;
     const uint32_t wpb = blockDim.x >> 6;
-    if (blockIdx.x >= a.step_blocks) {
+    if (blk >= a.step_blocks) {
         // the tail of the grid: one wavefront per node of the combine trees of this launch's hub rows; every node
         // waits for the partial sums it adds (hub pieces below announce theirs through the same flags)
         constexpr int FVEC = DP >= 64u ? (int)(DP / 64u) : 1;
         FinalizeTreeArgs ft;
         ft.f.X = a.X; ft.f.partials = a.partials; ft.f.Xn = a.Xn; ft.f.items = a.fin_items; ft.f.n_items = a.fin_n; ft.f.D = D;
         ft.f.push = a.push;
-        ft.ready = a.ready; ft.err = a.err; ft.timeout_ticks = a.timeout_ticks; ft.seq = a.seq; ft.first_dep = 0u;
-        const uint32_t node = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x - a.step_blocks) * wpb + (threadIdx.x >> 6)));
-        finalize_tree_node<OPT, FVEC, (FULL && DP % 64u == 0u)>(ft, node, lane);
+        ft.ready = a.ready; ft.err = a.err; ft.timeout_ticks = a.timeout_ticks; ft.seq = a.seq; ft.first_dep = 0u; ft.rowflag = a.rowflag;
+        const uint32_t node = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blk - a.step_blocks) * wpb + (threadIdx.x >> 6)));
+        finalize_tree_node<OPT, FVEC, (FULL && DP % 64u == 0u), CHAIN>(ft, node, lane);
         return;
     }
-    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + (threadIdx.x >> 6)));
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blk * wpb + (threadIdx.x >> 6)));
 
     // The minibatch's negative samples are the same ns rows for every item (except with -bs 1): the workgroup
     // stages them in LDS once -- each CU then fetches them from L2 once per workgroup instead of once per item, and
@@ -780,14 +827,24 @@ __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
     if constexpr (OPT != 5) {
         for (uint32_t k = threadIdx.x; k < 2048u; k += blockDim.x) sm_lds[k] = a.sm_table[k];
     }
+    bool smp_bad = false;
     if (lds_samples) {
         for (uint32_t k = threadIdx.x; k < a.ns * (DP / 4); k += blockDim.x) {
             const uint32_t sidx = k / (DP / 4), c4 = k % (DP / 4);
+            if constexpr (CHAIN) {
+                const uint32_t sj = a.sample_ids[sidx];
+                if ((sj - a.chain_lo) < a.chain_rows) smp_bad = wait_row(a, sj) || smp_bad;
+            }
             smp[sidx][c4] = (FULL || 4u * c4 < D) ? reinterpret_cast<const float4 *>(row_src(a, a.sample_ids[sidx], D))[c4]
                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    if (lds_samples || OPT != 5) __syncthreads();
+    if constexpr (CHAIN) {
+        // a sample row that never arrived poisons the whole workgroup: nobody stores
+        if (__syncthreads_or(smp_bad ? 1 : 0)) return;
+    } else {
+        if (lds_samples || OPT != 5) __syncthreads();
+    }
     const float *table = OPT == 5 ? a.sm_table : sm_lds;
     if (IPW * w >= a.n_items) return;
 
@@ -827,7 +884,8 @@ __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
         c0 = (double)(a.lr * degi);
     }
 
-    qprocess<OPT, LPI, NB, false, U, FULL>(a, a.nbr_ids + it.nb, it.cnt, wave_max_of_items<LPI>(it.cnt), t, D, xi, Y, c0, table);
+    bool bad = false;  // chained minibatches: a wait for an earlier minibatch's row gave up -- this item stores nothing
+    qprocess<OPT, LPI, NB, false, U, FULL, CHAIN>(a, a.nbr_ids + it.nb, it.cnt, wave_max_of_items<LPI>(it.cnt), t, D, xi, Y, c0, table, bad);
     if (lds_samples) {
         if (active && last_chunk) {
             for (uint32_t sidx = 0; sidx < a.ns; ++sidx) {
@@ -840,9 +898,13 @@ __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
     } else {
         const uint32_t scnt = (active && last_chunk) ? a.ns : 0u;
         const uint32_t sbase = a.bs_mode ? (row - a.batch_lo) : 0u;
-        qprocess<OPT, LPI, NB, true, U, FULL>(a, a.sample_ids + sbase, scnt, wave_max_of_items<LPI>(scnt), t, D, xi, Y, c0, table);
+        qprocess<OPT, LPI, NB, true, U, FULL, CHAIN>(a, a.sample_ids + sbase, scnt, wave_max_of_items<LPI>(scnt), t, D, xi, Y, c0, table, bad);
     }
 
+    if (CHAIN && __builtin_amdgcn_ballot_w64(bad) != 0ull) {
+        // (wave-uniform on purpose: the launch is lost anyway, and a wave either announces all its items or none)
+        return;
+    }
     if (active) {
         float *out = (partial ? a.partials + (size_t)(it.flags & kItemSlotMask) * D : a.Xn + (size_t)row * D) + t * 4;
         float4 v[NB];
@@ -853,7 +915,7 @@ __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
             else
                 v[b] = make_float4(Y[b][0], Y[b][1], Y[b][2], Y[b][3]);
             if (!FULL && !(4u * LPI * b + 4u * t < D)) continue;
-            if (partial && a.fin_items) store16_agent(out + 4 * LPI * b, v[b]);  // a tree node of this grid reads it
+            if ((partial && a.fin_items) || CHAIN) store16_agent(out + 4 * LPI * b, v[b]);  // a tree node (or a later minibatch) of this grid reads it
             else *reinterpret_cast<float4 *>(out + 4 * LPI * b) = v[b];
         }
         if constexpr (PUSH) {
@@ -875,6 +937,10 @@ __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
         }
     }
     if constexpr (PUSH) __builtin_amdgcn_s_waitcnt(0);  // the peers' memory has acknowledged this wave's rows
+    if constexpr (CHAIN) {
+        __builtin_amdgcn_s_waitcnt(0);  // new rows are in memory before they are announced to the later minibatches of the launch
+        if (active && !partial && t == 0u) __hip_atomic_store(a.rowflag + row, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (a.fin_items) {
         __builtin_amdgcn_s_waitcnt(0);  // partial sums are in memory before they are announced
 #ifdef F2V_TEST_HOOKS
@@ -882,6 +948,69 @@ __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
 #endif
         if (active && partial && t == 0u) __hip_atomic_store(a.ready + (it.flags & kItemSlotMask), a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+template <int OPT, int LPI, int NB, int U, bool PUSH = false, bool FULL = true>
+__global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
+    qstep_body<OPT, LPI, NB, U, PUSH, FULL, false>(a, blockIdx.x);
+}
+
+// ---- chained minibatches: several consecutive minibatches in ONE launch ---------------------------------------------
+// A small minibatch (the reference's default is 384 rows) is a few microseconds of work, but as a dependent launch of its
+// own it costs ~6 us of launch boundary on top: at batch 256 the engine was bound by that chain.  Here one launch covers many
+// consecutive minibatches (workgroups batch-major, in index order) and the Gauss-Seidel order between them is kept by DATA
+// dependencies at ROW granularity instead of launch boundaries: an item reads neighbour (or negative-sample) row j
+//   * from the first matrix if j has not been updated this epoch (as always),
+//   * from the second matrix if an earlier LAUNCH updated it (as always),
+//   * and if an earlier minibatch of THIS launch updates it -- j in [chain_lo, its own minibatch's first row) -- from the
+//     second matrix AFTER waiting for rowflag[j] == seq, which j's writer (its whole-row item, or the root of its combine
+//     tree) stores once the written-through row (sc1) has been acknowledged.
+// On RMAT-20 at batch 256 about 1.6 % of the neighbours are such rows; everything else runs ahead of the chain, and the
+// chain itself is the row-level dependency chain (hubs read hubs: ~24 deep in 64 minibatches), not one hop per minibatch.
+//   no stale lines   a row of the second matrix is never read before its writer has announced it (it is outside the
+//                    updated range until then), so no cache of the reading XCD can hold an older copy of its lines; rows are
+//                    whole 128-byte lines (D a multiple of 32 -- other D keep one launch per minibatch); plain loads follow
+//                    the (L1-bypassing) poll
+//   progress         an item only ever waits for rows of workgroups with a smaller index, and every XCD starts its
+//                    workgroups in index order (checked by f2v_create's dispatch probe): the lowest unfinished one can
+//                    always run; all waits are bounded by "tree_timeout_ms" all the same (err = 3: nothing is stored from
+//                    there on, the launch drains, f2v_train fails within an epoch)
+struct WgDesc {
+    uint32_t batch;  // minibatch of the launch
+    uint32_t blk;    // workgroup index inside that minibatch's grid (step items first, then tree nodes)
+};
+struct BatchDesc {
+    uint32_t lo;           // first row of the minibatch
+    uint32_t item_off;     // its items (offset into the launch's item array), n_items of them
+    uint32_t n_items;
+    uint32_t step_blocks;  // workgroups that step items; the rest of its n_wgs run tree nodes
+    uint32_t fin_off, fin_n;
+    uint32_t n_wgs;
+    uint32_t index;        // global minibatch index of the epoch: which sample ids
+};
+struct ChainArgs {
+    StepArgs base;            // what all minibatches share; items / fin_items point at the launch's arrays
+    const WgDesc *wg;
+    const BatchDesc *batch;
+    const uint32_t *ids;      // the epoch's sample ids, `ids_stride` per minibatch
+    uint32_t ids_stride;
+};
+
+template <int OPT, int LPI, int NB, int U, bool FULL>
+__global__ __launch_bounds__(256) void qstep_chain_kernel(const ChainArgs c) {
+    const WgDesc wd = c.wg[blockIdx.x];
+    const BatchDesc bd = c.batch[wd.batch];
+    StepArgs a = c.base;
+    a.batch_lo = bd.lo;
+    a.upd_rows = bd.lo - a.upd_lo;      // rows [upd_lo, this minibatch's first row) are read from the second matrix ...
+    a.chain_rows = bd.lo - a.chain_lo;  // ... those from chain_lo on after waiting for their flag
+    a.sample_ids = c.ids + (size_t)bd.index * c.ids_stride;
+    a.items = c.base.items + bd.item_off;
+    a.n_items = bd.n_items;
+    a.step_blocks = bd.step_blocks;
+    a.fin_items = bd.fin_n ? c.base.fin_items + bd.fin_off : nullptr;
+    a.fin_n = bd.fin_n;
+    qstep_body<OPT, LPI, NB, U, false, FULL, true>(a, wd.blk);
 }
 
 // One level of the hub combine trees of a launch: every item adds up to `fanin` partial rows in
