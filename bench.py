@@ -261,7 +261,7 @@ def main():
         # Before this process touches the GPU: a throw-away child rehearses the IPC mapping and the remote stores the push
         # exchange needs (the ranks' children meet through files).  If it fails, faults or never returns, the run uses RCCL.
         mbytes = ((1 << args.scale) + 4096) * args.dim * 4
-        if mbytes >= 0x7FF00000:
+        if mbytes >= 1 << 31:  # kIpcMaxBytes of f2v_engine.hip
             mbytes = 2 * min(512 << 20, mbytes // 2)  # such engines map a landing buffer instead of the matrices
         pre_dev = 0 if args.dist_backend == "gloo" else local_rank
         # where the ranks' children meet: all ranks are children of one launcher (torch.distributed.run), whose pid makes

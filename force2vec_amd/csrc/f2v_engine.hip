@@ -14,7 +14,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <condition_variable>
 #include <map>
+#include <mutex>
 #include <memory>
 #include <string>
 #include <thread>
@@ -39,6 +42,7 @@ using namespace f2v;
                         hipGetErrorString(e__), __FILE__, __LINE__);                                   \
     } while (0)
 
+constexpr size_t kIpcMaxBytes = (size_t)1 << 31;  // allocations of this size and more cannot be opened through HIP IPC (f2v_push_export)
 constexpr uint32_t kPadRows = 4096;  // slack behind row N for the padded in-place all-gather of the last minibatch
 constexpr int kMaxFinLevels = 32;  // fan-in >= 2: 2^32 chunks
 struct Plan {
@@ -82,6 +86,7 @@ struct f2v_ctx {
     bool exact = false;
     std::vector<uint32_t> rowptr, colids;  // host copies: hub planning, walk generation, statistics
     uint32_t *d_rowptr = nullptr, *d_colids = nullptr, *d_walks = nullptr, *d_ids = nullptr;
+    uint32_t *d_walks_alt = nullptr;  // second walk buffer: f2v_train (option 7) alternates between the two, epoch by epoch
     size_t ids_cap = 0, ids_valid = 0;  // ids_valid: prefix uploaded by f2v_upload_sample_ids
     float *d_X[2] = {nullptr, nullptr}, *d_partials = nullptr, *d_table = nullptr;
     uint32_t *d_ready = nullptr, *d_kerr = nullptr;  // combine-tree flags (one per partial slot), kernel error word
@@ -1192,7 +1197,7 @@ int f2v_destroy(f2v_handle c) {
     if (!c) return F2V_OK;
     (void)hipSetDevice(c->device);
     (void)push_detach(c);
-    void *ptrs[] = {c->d_rowptr, c->d_colids, c->d_walks, c->d_ids, c->d_X[0], c->d_X[1],
+    void *ptrs[] = {c->d_rowptr, c->d_colids, c->d_walks, c->d_walks_alt, c->d_ids, c->d_X[0], c->d_X[1],
                     c->d_partials, c->d_table, c->d_items, c->d_hubs, c->d_ready, c->d_kerr, c->d_wg, c->d_bdesc, c->d_rowflag, c->push.flags, c->push.d_err, c->push.d_masks, c->push.d_patch, c->push.landing_buf};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1830,21 +1835,107 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
         HIPC(hipStreamSynchronize(c->stream));
         for (int par = 0; par < 2; par++) { (void)hipGraphExecDestroy(exec[par]); (void)hipGraphDestroy(graph[par]); }
     }
+    // Epochs whose host-side inputs cannot all be drawn up-front (option 7: the walks are 5 N ids per epoch, and the one serial
+    // rand() stream interleaves them with the sample ids): a producer thread draws epoch e+1's walks and ids -- they never depend
+    // on the embeddings (sample/algorithms.cpp:1097-1132) -- into pinned buffers while the device runs epoch e; the copies are
+    // stream-ordered asynchronous copies into alternating device buffers, and nothing in the loop waits for the device.
+    // Epoch time = max(host generation, device), instead of their sum plus two synchronisations.
+    struct HostEpoch {
+        uint32_t *walks = nullptr, *ids = nullptr;  // pinned
+        hipEvent_t copied = nullptr;                // the H2D copies out of this slot have completed
+        bool full = false, copy_pending = false;
+    } slot[2];
+    std::mutex mu;
+    std::condition_variable cv;
+    std::thread producer;
+    bool stop_producer = false;
+    const bool host_walks = (math == 7 && !c->fast_rng);
+    const bool produced = !all_upfront && !graphed && iters > 0;
+    uint32_t *d_walk_buf[2] = {nullptr, nullptr};
+    auto end_producer = [&] {
+        if (producer.joinable()) {
+            { std::lock_guard<std::mutex> lk(mu); stop_producer = true; }
+            cv.notify_all();
+            producer.join();
+        }
+        if (slot[0].copy_pending || slot[1].copy_pending) (void)hipStreamSynchronize(c->stream);  // no copy still reads the pinned buffers
+        for (auto &sl : slot) {
+            if (sl.walks) (void)hipHostFree(sl.walks);
+            if (sl.ids) (void)hipHostFree(sl.ids);
+            if (sl.copied) (void)hipEventDestroy(sl.copied);
+            sl = HostEpoch{};
+        }
+    };
+    struct AtExit {
+        std::function<void()> f;
+        ~AtExit() { f(); }
+    } producer_guard{end_producer};  // every return below joins the thread and frees the pinned buffers
+    if (produced) {
+        const size_t nwalk = (size_t)n * kWalkLength;
+        if (host_walks) {
+            if (!c->d_walks) HIPC(hipMalloc((void **)&c->d_walks, nwalk * sizeof(uint32_t)));
+            if (!c->d_walks_alt) HIPC(hipMalloc((void **)&c->d_walks_alt, nwalk * sizeof(uint32_t)));
+            d_walk_buf[0] = c->d_walks;
+            d_walk_buf[1] = c->d_walks_alt;
+        }
+        if ((rc = reserve_ids(c, std::max<uint64_t>(2 * per_epoch, 64))) != F2V_OK) return rc;
+        for (auto &sl : slot) {
+            if (host_walks) HIPC(hipHostMalloc((void **)&sl.walks, nwalk * sizeof(uint32_t), hipHostMallocDefault));
+            HIPC(hipHostMalloc((void **)&sl.ids, std::max<size_t>(per_epoch, 1) * sizeof(uint32_t), hipHostMallocDefault));
+            HIPC(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
+        }
+        const int dev = c->device;
+        producer = std::thread([&, dev] {
+            (void)hipSetDevice(dev);
+            std::vector<uint32_t> w, v(per_epoch);
+            for (uint32_t it = 0; it < iters; it++) {
+                HostEpoch &sl = slot[it & 1];
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return stop_producer || !sl.full; });
+                    if (stop_producer) return;
+                }
+                if (sl.copy_pending) { (void)hipEventSynchronize(sl.copied); sl.copy_pending = false; }  // the slot's last copies have left it
+                if (host_walks) {  // the reference's order: the epoch's walks, then its minibatches' sample ids
+                    generate_walks_host(c, w);
+                    memcpy(sl.walks, w.data(), w.size() * sizeof(uint32_t));
+                }
+                draw_epoch(v, 0);
+                if (per_epoch) memcpy(sl.ids, v.data(), per_epoch * sizeof(uint32_t));
+                { std::lock_guard<std::mutex> lk(mu); sl.full = true; }
+                cv.notify_all();
+            }
+        });
+    }
     for (uint32_t it = 0; it < iters && !graphed; it++) {
         if (math == 7 && c->fast_rng) {
             if ((rc = fast_walks(c)) != F2V_OK) return rc;  // stream-ordered: no host work, no synchronisation
-        } else if (math == 7) {
-            generate_walks_host(c, walks);
-            if (!c->d_walks) HIPC(hipMalloc((void **)&c->d_walks, walks.size() * sizeof(uint32_t)));
-            HIPC(hipStreamSynchronize(c->stream));  // previous epoch's steps read d_walks / d_ids
-            HIPC(hipMemcpy(c->d_walks, walks.data(), walks.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-            c->have_walks = true;
         }
-        const uint32_t *d_epoch_ids = c->d_ids + (all_upfront ? (size_t)it * per_epoch : 0);
-        if (!all_upfront) {
-            draw_epoch(ids, 0);
-            HIPC(hipStreamSynchronize(c->stream));
-            HIPC(hipMemcpy(c->d_ids, ids.data(), ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        const uint32_t *d_epoch_ids = c->d_ids + (all_upfront ? (size_t)it * per_epoch : (size_t)(it & 1) * per_epoch);
+        if (produced) {
+            HostEpoch &sl = slot[it & 1];
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return sl.full; });
+            }
+            // stream-ordered behind epoch it-2's kernels, the last readers of these device buffers
+            hipError_t he = hipSuccess;
+            if (host_walks) {
+                he = hipMemcpyAsync(d_walk_buf[it & 1], sl.walks, (size_t)n * kWalkLength * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+                c->d_walks = d_walk_buf[it & 1];
+                c->d_walks_alt = d_walk_buf[(it & 1) ^ 1];
+                c->have_walks = true;
+            }
+            if (he == hipSuccess && per_epoch)
+                he = hipMemcpyAsync(c->d_ids + (size_t)(it & 1) * per_epoch, sl.ids, per_epoch * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+            if (he == hipSuccess) he = hipEventRecord(sl.copied, c->stream);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                sl.copy_pending = true;
+                sl.full = false;
+            }
+            cv.notify_all();
+            HIPC(he);
         }
         if (chained) {
             for (uint32_t b0 = 0; b0 < nb; b0 += K) {
@@ -1945,7 +2036,14 @@ int f2v_push_export(f2v_handle c, void *handles_out) {
     c->push.round = 0;
     PushExport e{};
     const size_t matrix_bytes = ((size_t)c->n + kPadRows) * c->D * sizeof(float);
-    c->push.landing = c->push.force_landing || matrix_bytes >= (size_t)0x7FF00000;  // 2 GiB and more cannot be mapped (see Push)
+    // What HIP IPC can map.  Evidence (tools/ipc_probe.py, ROCm 7.2, dmabuf IPC, HSA_ENABLE_IPC_MODE_LEGACY=0): an allocation one
+    // row below 2^31 bytes attaches in a millisecond, one row above 2^31 bytes never returns from hipIpcOpenMemHandle -- the
+    // step is at exactly 2^31 BYTES OF ALLOCATION SIZE, whatever the row count, padding or matrix contents, and the 4-KiB
+    // fine-grained flag array and the landing buffers (<= 1 GiB) always attach: a signed 32-bit size on the import path of the
+    // IPC handle, not a property of peer access or of lazy enabling (the same flag maps the small allocations).  So the
+    // threshold IS that number; tests/test_gpu_large.py attaches one matrix just below it directly and one just above it
+    // through the landing buffer.  Only ever observed with both processes on one GPU (no multi-GPU box was available).
+    c->push.landing = c->push.force_landing || matrix_bytes >= kIpcMaxBytes;
     if (c->push.landing) {
         // two halves of at most 512 MiB; room for the self-test's `world` pattern rows in any case
         const size_t per_row = (size_t)c->D * sizeof(float);

@@ -28,6 +28,49 @@ def math_of_option(option):
     return {5: 5, 8: 5, 11: 5, 6: 6, 9: 6, 7: 7, 10: 7}[option]
 
 
+def vertex_partition(n, world, batch):
+    """1-D vertex partition (second mode): rank g OWNS a contiguous range of vertices and steps its own local
+    minibatch k (`batch` rows) at the same time as every other rank steps ITS local minibatch k; after the step the world*batch
+    new rows are exchanged.  That is, row for row, the reference's algorithm on a RELABELLED graph -- super-minibatch k is the
+    union of the ranks' local minibatches k, laid out rank after rank -- with batch size world*batch and the same sample-index
+    stream; and it is what ShardedTrainer does on that graph, whose equal-count slice r of every minibatch is rank r's own local
+    minibatch.  -> (start uint64[world+1]: rank g owns original vertices [start[g], start[g+1]),
+                    new_id int64[n]: position of original vertex v in the relabelled graph).
+    All super-minibatches but the last are full (world*batch rows); the last one's rows are split like any minibatch's
+    (shard_bounds), so rank sizes differ by at most one minibatch's rounding."""
+    big = world * batch
+    nfull = (n - 1) // big if n > 0 else 0          # full super-minibatches
+    rest = n - nfull * big                          # rows of the last one (1..big)
+    sizes, last = [], []
+    for g in range(world):
+        _, a, b = shard_bounds(0, rest, g, world)
+        last.append((a, b))
+        sizes.append(nfull * batch + (b - a))
+    start = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    new_id = np.empty(n, dtype=np.int64)
+    for g in range(world):
+        local = np.arange(sizes[g], dtype=np.int64)
+        k, p = local // batch, local % batch
+        full = k < nfull
+        ids = np.where(full, k * big + g * batch + p, nfull * big + last[g][0] + (local - nfull * batch))
+        new_id[start[g]: start[g + 1]] = ids
+    return start, new_id
+
+
+def relabel_csr(rowptr, colids, new_id):
+    """The same graph with vertex v renamed new_id[v]: rows in the new order, neighbour ids ascending inside a row, duplicates kept."""
+    n = len(rowptr) - 1
+    deg = np.diff(rowptr.astype(np.int64))
+    old_of_new = np.empty(n, dtype=np.int64)
+    old_of_new[new_id] = np.arange(n, dtype=np.int64)
+    rows_new = np.repeat(new_id, deg)                  # new id of every nonzero's row, in the old order
+    cols_new = new_id[colids.astype(np.int64)]
+    order = np.lexsort((cols_new, rows_new))
+    rp = np.zeros(n + 1, dtype=np.int64)
+    rp[1:] = np.cumsum(deg[old_of_new])
+    return rp.astype(np.uint32), cols_new[order].astype(np.uint32)
+
+
 class HostStageComm:
     """All-gather of the staged rows through host memory (any torch.distributed backend, e.g. gloo)."""
 

@@ -106,3 +106,65 @@ def test_shard_bounds_cover_the_batch():
                 assert lo <= a <= b <= hi and b - a <= per
                 seen += list(range(a, b))
             assert seen == list(range(lo, hi)) and len(pers) == 1
+
+
+def _partition_worker(rank, world, port, graph, option, iters, batch, dim, outdir):
+    import torch.distributed as dist
+    from fake_engine import OracleEngine
+    from force2vec_amd import dist as fdist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    rp, ci = O.read_mtx(golden_graph_path(graph))
+    start, new_id = fdist.vertex_partition(len(rp) - 1, world, batch)
+    rp2, ci2 = fdist.relabel_csr(rp, ci, new_id)
+    eng = OracleEngine(rp2, ci2, dim, chunk=4)
+    eng.srand(1)
+    eng.init_embeddings(0 if option == 5 else 1)
+    fdist.ShardedTrainer(eng, rank, world, fdist.HostStageComm(dist, rank, world)).train(option, iters, world * batch, 5, 0.02, 0)
+    np.save(os.path.join(outdir, "r%d.npy" % rank), eng.get_embeddings())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("graph,option,batch,world", [("cora.mtx", 5, 128, 2), ("karate.mtx", 6, 5, 3), ("cora.mtx", 6, 300, 2)])
+def test_vertex_partition_mode_is_the_reference_on_the_relabelled_graph(graph, option, batch, world, tmp_path):
+    """SURVEY 8e, second mode: every rank owns a contiguous vertex range and steps its own local minibatch k while the others
+    step theirs.  force2vec_amd.dist.vertex_partition gives the relabelling under which that is the reference's algorithm
+    with batch world*B; checked as the survey prescribes: (1) the sharded run on the relabelled graph gives, on every rank,
+    exactly what the oracle gives on the relabelled graph with -batch world*B; (2) in every minibatch, rank r's slice is a
+    contiguous run of ITS OWN original vertices; (3) where the genuine reference binary is present, it agrees on the permuted
+    .mtx (fp32 order tolerance)."""
+    import torch.multiprocessing as mp
+    from force2vec_amd import dist as fdist
+    from force2vec_amd.graph import edges_from_csr, write_mtx_symmetric
+    dim, iters = 16, 3
+    rp, ci = O.read_mtx(golden_graph_path(graph))
+    n = len(rp) - 1
+    start, new_id = fdist.vertex_partition(n, world, batch)
+    assert sorted(new_id.tolist()) == list(range(n)) and start[0] == 0 and start[-1] == n
+    old_of_new = np.empty(n, dtype=np.int64)
+    old_of_new[new_id] = np.arange(n)
+    big = world * batch
+    for lo in range(0, n, big):
+        hi = min(lo + big, n)
+        for r in range(world):
+            _, a, b = fdist.shard_bounds(lo, hi, r, world)
+            mine = old_of_new[a:b]
+            assert np.all((mine >= start[r]) & (mine < start[r + 1])) and np.all(np.diff(mine) == 1)
+    rp2, ci2 = fdist.relabel_csr(rp, ci, new_id)
+    # the relabelled CSR is the same graph: edge (u, v) <-> (new_id[u], new_id[v]), neighbour ids ascending
+    deg2 = np.diff(rp2.astype(np.int64))
+    assert np.array_equal(deg2[new_id], np.diff(rp.astype(np.int64)))
+    for v in (0, n // 2, n - 1):
+        assert sorted(new_id[ci[rp[v]:rp[v + 1]].astype(np.int64)].tolist()) == ci2[rp2[new_id[v]]:rp2[new_id[v] + 1]].tolist()
+    mp.spawn(_partition_worker, args=(world, _free_port(), graph, option, iters, batch, dim, str(tmp_path)), nprocs=world, join=True)
+    want = O.train(option, rp2, ci2, dim, iters, big, order=O.ORDER_TREE, chunk=4)
+    for r in range(world):
+        assert np.array_equal(np.load(str(tmp_path / ("r%d.npy" % r))), want)
+    if O.ref_binary() is not None:
+        mtx = str(tmp_path / "permuted.mtx")
+        src, dst = edges_from_csr(rp2, ci2)
+        write_mtx_symmetric(mtx, n, src, dst)
+        rp3, ci3 = O.read_mtx(mtx)
+        assert np.array_equal(rp3, rp2) and np.array_equal(ci3, ci2)  # what the reference will read is the relabelled graph
+        path, _ = O.run_reference(mtx, str(tmp_path), option, iters, big, dim)
+        assert np.abs(O.read_embd(path) - want).max() < 1e-5

@@ -145,3 +145,70 @@ def test_push_exchange_lands_at_2gib(tmp_path):
     for r in range(2):
         z = np.load(str(tmp_path / ("r%d.npz" % r)))
         assert np.array_equal(z["sums"], sums) and np.array_equal(z["sample"], sample)
+
+
+def _boundary_worker(rank, world, port, n, expect_landing, outdir):
+    import torch.distributed as dist
+    import force2vec_amd as F
+    from force2vec_amd import dist as fdist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    z = np.load("/tmp/f2v_test_ring%d.npz" % n)
+    eng = F.Engine(z["rowptr"], z["colids"], 128, device=0)
+    eng.set_param("fast_rng", 1)  # 2 GiB of rand() draws are not the point here
+    eng.srand(1)
+    eng.init_embeddings(0)
+    eng.set_param("push_timeout_ms", 20000)
+    comm = fdist.PushExchange(dist, rank, world)
+    comm.attach(eng)
+    assert eng.get_param("push_landing") == expect_landing
+    fdist.ShardedTrainer(eng, rank, world, comm).train(5, 1, 1 << 20, 5, 0.02, 0)
+    X = eng.get_embeddings()
+    np.savez(os.path.join(outdir, "r%d.npz" % rank), sums=X.sum(axis=1, dtype=np.float64), sample=X[::1009].copy())
+    comm.detach(eng)
+    eng.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("where", ["just_below_2GiB", "just_above_2GiB"])
+def test_ipc_mapping_boundary(where, tmp_path):
+    """hipIpcOpenMemHandle cannot open allocations of 2^31 bytes and more (f2v_push_export: kIpcMaxBytes).  A matrix ONE ROW
+    below that size is attached directly (the peers map both matrices), one row above it goes through the landing buffer --
+    chosen by the engine from the size alone -- and both give the single-GPU result.  A mapping call that hangs is cut off
+    by the join time-out instead of stalling the suite."""
+    import torch.multiprocessing as mp
+    import force2vec_amd as F
+    n = (1 << 22) - 4096 + (-1 if where == "just_below_2GiB" else 1)  # (n + 4096 padding rows) * 512 bytes = 2^31 -/+ 512
+    assert ((n + 4096) * 512 < 1 << 31) == (where == "just_below_2GiB")
+
+    def ring():  # every vertex linked to its two neighbours on a ring and to one far vertex: cheap to build, rows all alike
+        v = np.arange(n, dtype=np.int64)
+        far = (v * 7919 + 13) % n
+        r = np.concatenate([v, v, v, far])
+        c = np.concatenate([(v + 1) % n, (v - 1) % n, far, v])
+        keep = r != c
+        r, c = r[keep], c[keep]
+        order = np.lexsort((c, r))
+        rowptr = np.zeros(n + 1, dtype=np.int64)
+        rowptr[1:] = np.cumsum(np.bincount(r, minlength=n))
+        return rowptr.astype(np.uint32), c[order].astype(np.uint32)
+    rowptr, colids = cached_graph("ring%d" % n, ring)
+    ctx = mp.spawn(_boundary_worker, args=(2, _free_port(), n, 0 if where == "just_below_2GiB" else 1, str(tmp_path)), nprocs=2, join=False)
+    import time
+    t0 = time.time()
+    while not ctx.join(timeout=5):
+        if time.time() - t0 > 240:
+            for p in ctx.processes:
+                p.kill()
+            pytest.fail("attaching a matrix %s did not finish in 240 s (a hipIpcOpenMemHandle that never returns?)" % where)
+    eng = F.Engine(rowptr, colids, 128)
+    eng.set_param("fast_rng", 1)
+    eng.srand(1)
+    eng.init_embeddings(0)
+    eng.set_param("hub_chunk_for_batch", (1 << 20) // 2)  # the chunk a rank of two picks for its slice (no row is split here anyway)
+    eng.train(5, 1, 1 << 20)
+    X = eng.get_embeddings()
+    eng.close()
+    for r in range(2):
+        z = np.load(str(tmp_path / ("r%d.npz" % r)))
+        assert np.array_equal(z["sums"], X.sum(axis=1, dtype=np.float64)) and np.array_equal(z["sample"], X[::1009])
