@@ -392,14 +392,15 @@ def main():
 
         def run_epochs(self, k, batch):
             """-> per-rank statistics of these k epochs (launches, bytes, device seconds where known)."""
-            self.schedule.append((k, batch))
             eng = self.eng
             if not use_dist:
                 eng.train(self.option, k, batch, 5, 0.02, 0)
+                self.schedule.append((k, batch, eng.get_param("hub_chunk")))
                 return eng.stats()
             s0 = eng.stats()
             comm = self.make_comm()
             fdist.ShardedTrainer(eng, rank, world, comm, exchange_when_single=True).train(self.option, k, batch, 5, 0.02, 0)
+            self.schedule.append((k, batch, eng.get_param("hub_chunk")))  # the chunk this call ran with: part of the summation order
             s1 = eng.stats()
             if self.state["exchange"] == "push":
                 st = dict(s1)  # f2v_train_sharded restarts the statistics like f2v_train
@@ -461,11 +462,11 @@ def main():
                 pk, pv = kv.split("=")
                 if not pk.startswith("push_"):
                     ref.set_param(pk, int(pv))
-            ref.set_param("hub_chunk", self.eng.get_param("hub_chunk"))  # the chunk is part of the summation order
             ref.srand(1)
             ref.init_embeddings(self.init_kind)
-            for i, (k, b) in enumerate(self.schedule):
+            for i, (k, b, chunk) in enumerate(self.schedule):
                 try:
+                    ref.set_param("hub_chunk", chunk)  # the chunk is part of the summation order (a sharded run picks it per slice)
                     ref.train(self.option, k, b, 5, 0.02, 0)
                 except Exception:
                     note(rank, "single-GPU replay failed in call %d of %d (%d epochs at batch %d)" % (i, len(self.schedule), k, b))
@@ -492,7 +493,7 @@ def main():
         verified = None
         if use_dist and not args.no_verify:
             verified = sess.verify_replica()
-            note(rank, "replica compared with a single-GPU run of the same %d epochs: %s" % (sum(k for k, _ in sess.schedule), "identical" if verified else "DIFFERENT"))
+            note(rank, "replica compared with a single-GPU run of the same %d epochs: %s" % (sum(e[0] for e in sess.schedule), "identical" if verified else "DIFFERENT"))
             if not verified:
                 failed.append("%s exchange: replica differs from the single-GPU run (option %d, batch %d, n=%d)" % (sess.state["exchange"], sess.option, batch, sess.n))
                 if sess.state["exchange"] == "push":
