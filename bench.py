@@ -241,6 +241,12 @@ def main():
     ap.add_argument("--config5-batch", type=int, default=1048576)
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON result: whatever libraries print there meanwhile (gloo announces its
+    # connections on stdout) goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -654,7 +660,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(res), flush=True)
+        print(json.dumps(res), file=real_stdout, flush=True)
     if failed:
         sys.exit(3)
 

@@ -131,6 +131,7 @@ struct f2v_ctx {
     bool fast_rng = false;        // non-parity mode: device-side init and option-7 walks (counter-based RNG)
     uint64_t fast_seed = 1, fast_epoch = 0;
     int rows_in_flight = 4;
+    bool class_cut = true;         // split rows are also cut where their neighbour ids cross into the next eighth of the id range (piece_cuts)
     bool piece_affinity = true;    // hub pieces are placed on the XCD that owns their neighbours' id range (see plan_for)
     bool shared_card = false;      // a peer of the push exchange runs on the same GPU: placement goes back to same-XCD groups
     bool count_compulsory = false;  // plans also count their compulsory bytes (f2v_stats.compulsory_bytes; costs O(nnz) per new plan)
@@ -213,6 +214,35 @@ uint32_t items_per_block(const f2v_ctx *c) {
     return per_wave * (uint32_t)c->waves_per_block;
 }
 
+// Where a split row (degree > chunk) is cut into pieces: after every `chunk` neighbours, and -- "class_cut", the default --
+// also wherever the (ascending) neighbour ids cross from one eighth of the id range into the next, so that all neighbours of
+// a piece belong to ONE of the kIdClasses id ranges and the piece can run on the XCD whose L2 caches that range
+// ("piece_affinity").  The cuts are part of the summation order (a piece accumulates from zero, the pieces' sums are combined
+// in order): the oracle restates exactly this rule (oracle/f2v_oracle.c: piece_cuts), and it depends on nothing but the
+// row's neighbour ids, the chunk and N -- not on the machine, the placement or the number of GPUs.
+// Appends the offsets of the pieces' first neighbours and, last, the degree.
+constexpr uint32_t kIdClasses = 8;
+void piece_cuts(const f2v_ctx *c, uint32_t row, std::vector<uint32_t> &cuts) {
+    const uint32_t rp = c->rowptr[row], deg = c->rowptr[row + 1] - rp;
+    if (!c->class_cut) {
+        for (uint32_t b = 0; b < deg; b += c->chunk) cuts.push_back(b);
+        cuts.push_back(deg);
+        return;
+    }
+    auto cls_of = [&](uint32_t e) { return (uint32_t)(((uint64_t)c->colids[rp + e] * kIdClasses) / c->n); };
+    uint32_t start = 0, cls = cls_of(0);
+    cuts.push_back(0);
+    for (uint32_t e = 1; e < deg; e++) {
+        const uint32_t ce = cls_of(e);
+        if (ce != cls || e - start == c->chunk) {
+            cuts.push_back(e);
+            start = e;
+            cls = ce;
+        }
+    }
+    cuts.push_back(deg);
+}
+
 // Compulsory bytes of one minibatch: every DISTINCT embedding row it reads (its own rows and their neighbours) once, every
 // row it writes once, its neighbour ids and work items once -- what would still cross HBM if everything read twice inside
 // the minibatch came from a cache the second time.  (The ns sampled rows, the partial sums of split rows and rowptr are
@@ -261,8 +291,9 @@ const Plan &plan_for(f2v_ctx *c, uint32_t row_lo, uint32_t row_hi, bool walk) {
     p.item_off = c->h_items.size();
     std::vector<Item> whole;  // rows that stay one item
     whole.reserve(row_hi - row_lo);
-    struct Node { uint32_t row, in_slot, n, cls; };
+    struct Node { uint32_t row, in_slot, n, cut; };  // cut: index of the row's first piece boundary in `cuts`
     std::vector<Node> cur, nxt;
+    std::vector<uint32_t> cuts;  // per split row: offsets of its pieces' first neighbours, then its degree
     uint32_t slots = 0;
     for (uint32_t i = row_lo; i < row_hi; i++) {
         if (walk) {
@@ -273,8 +304,10 @@ const Plan &plan_for(f2v_ctx *c, uint32_t row_lo, uint32_t row_hi, bool walk) {
         const uint32_t rp = c->rowptr[i], deg = c->rowptr[i + 1] - rp;
         p.nnz += deg;
         if (c->chunk != 0 && deg > c->chunk) {
-            const uint32_t nc = (deg + c->chunk - 1) / c->chunk;
-            cur.push_back(Node{i, slots, nc, 0});
+            const uint32_t cut0 = (uint32_t)cuts.size();
+            piece_cuts(c, i, cuts);
+            const uint32_t nc = (uint32_t)cuts.size() - cut0 - 1;
+            cur.push_back(Node{i, slots, nc, cut0});
             slots += nc;
         } else {
             whole.push_back(Item{i, rp, deg, kItemFirst | kItemLast});
@@ -297,7 +330,8 @@ const Plan &plan_for(f2v_ctx *c, uint32_t row_lo, uint32_t row_hi, bool walk) {
         std::vector<FinItem> nq[kXcds];
         uint64_t load[kXcds] = {}, aload[kXcds] = {};  // neighbours given to every class so far: a group goes to the lightest one
         for (const Node &nd : cur) {
-            const uint32_t rp = c->rowptr[nd.row], deg = c->rowptr[nd.row + 1] - rp;
+            const uint32_t rp = c->rowptr[nd.row];
+            const uint32_t *cut = cuts.data() + nd.cut;
             const uint32_t G = c->fanin < 2 ? nd.n : c->fanin;
             const uint32_t nout = (nd.n + G - 1) / G;
             for (uint32_t o = 0; o < nout; o++) {
@@ -305,9 +339,9 @@ const Plan &plan_for(f2v_ctx *c, uint32_t row_lo, uint32_t row_hi, bool walk) {
                 uint32_t cls = 0;
                 for (uint32_t k = 1; k < kXcds; k++)
                     if (load[k] < load[cls]) cls = k;
-                load[cls] += std::min(deg, k1 * c->chunk) - k0 * c->chunk;
+                load[cls] += cut[k1] - cut[k0];
                 for (uint32_t k = k0; k < k1; k++) {
-                    const uint32_t b = k * c->chunk, e = std::min(deg, b + c->chunk);
+                    const uint32_t b = cut[k], e = cut[k + 1];
                     // "piece_affinity" (DESIGN.md section 3): a piece goes to the XCD that owns the id range of its (ascending)
                     // neighbours -- the lightest of the XCDs whose ranges it touches: midpoints alone leave the outer ranges short
                     // of work and cost 40 % -- so that every L2 caches an eighth of the matrix instead of all eight the same
@@ -436,6 +470,7 @@ const ChainPlan &chain_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t ba
     std::vector<DI> items;
     struct Node { uint32_t row, in_slot, n; };
     std::vector<Node> cur, nxt;
+    std::vector<uint32_t> cutbuf;
     for (uint32_t k = 0; k < K; k++) {
         const uint32_t lo = (uint32_t)std::min<uint64_t>((uint64_t)(b0 + k) * batch, c->n);
         const uint32_t hi = (uint32_t)std::min<uint64_t>((uint64_t)lo + batch, c->n);
@@ -455,9 +490,11 @@ const ChainPlan &chain_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t ba
             const uint32_t rp = c->rowptr[i], deg = c->rowptr[i + 1] - rp;
             nnz += deg;
             if (c->chunk != 0 && deg > c->chunk) {
-                const uint32_t nc = (deg + c->chunk - 1) / c->chunk;
+                cutbuf.clear();
+                piece_cuts(c, i, cutbuf);
+                const uint32_t nc = (uint32_t)cutbuf.size() - 1;
                 for (uint32_t q = 0; q < nc; q++) {
-                    const uint32_t b = q * c->chunk, e = std::min(deg, b + c->chunk);
+                    const uint32_t b = cutbuf[q], e = cutbuf[q + 1];
                     items.push_back(DI{Item{i, rp + b, e - b, kItemPartial | (q == 0 ? kItemFirst : 0u) | (q == nc - 1 ? kItemLast : 0u) | (slots + q)}, dep_of(rp + b, rp + e)});
                 }
                 cur.push_back(Node{i, slots, nc});
@@ -1359,6 +1396,15 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
         c->use_graph = value != 0;
         return F2V_OK;
     }
+    if (!strcmp(name, "class_cut")) {
+        HIPC(hipSetDevice(c->device));
+        int rc = flush_pending(c);
+        if (rc != F2V_OK) return rc;
+        HIPC(hipStreamSynchronize(c->stream));
+        c->class_cut = value != 0;
+        drop_plans(c);
+        return F2V_OK;
+    }
     if (!strcmp(name, "piece_affinity")) {
         if (c->piece_affinity != (value != 0)) {
             HIPC(hipSetDevice(c->device));
@@ -1452,6 +1498,7 @@ int f2v_get_param(f2v_handle c, const char *name, int64_t *out) {
     if (!strcmp(name, "use_graph")) { *out = c->use_graph ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "count_compulsory")) { *out = c->count_compulsory ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "piece_affinity")) { *out = c->piece_affinity ? 1 : 0; return F2V_OK; }
+    if (!strcmp(name, "class_cut")) { *out = c->class_cut ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "shared_card")) { *out = c->shared_card ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "hub_chunk_auto")) { *out = c->chunk_auto ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "push_timeout_ms")) { *out = c->push.timeout_ms; return F2V_OK; }

@@ -66,7 +66,9 @@ int f2v_get_embeddings(f2v_handle h, float *x_out);
  * falls back to 0), 0 = one launch per tree level; f2v_create selects 0 by itself when its dispatch probe does not
  * find 8 XCDs taking workgroups round robin ("xcc_count", "xcc_round_robin" answer what it saw); "chain_batches" (default 1): f2v_train runs minibatches of up to "chain_max_batch" (512) rows in groups of
  * "chain_rows" (16384) rows per launch, ordered by row-level data dependencies inside the launch instead of launch boundaries
- * (same results; batch 256 on RMAT-20: 0.60 -> 1.06 G edges/s); "piece_affinity" (default 1): a split row's pieces run on the XCD that owns
+ * (same results; batch 256 on RMAT-20: 0.60 -> 1.06 G edges/s); "class_cut" (default 1): a split row's pieces also end where its ascending neighbour ids cross
+ * from one eighth of the id range into the next (part of the summation order, restated by the oracle; it is what makes
+ * "piece_affinity" pure); "piece_affinity" (default 1): a split row's pieces run on the XCD that owns
  * the id range of their neighbours, so that each of the eight L2s caches its own eighth of the matrix (placement only:
  * results do not change; ranks of a push exchange that share one GPU switch it off by themselves); "quarter_wave": 0 selects the one-item-per-wavefront
  * kernel for every D; "waves_per_block"; "rows_in_flight" (4|8); "use_graph" = 1 makes f2v_train replay a

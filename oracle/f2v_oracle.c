@@ -19,8 +19,11 @@
  *       canonical order of the HIP wavefront reduction (in-lane pairs, then lane xor
  *       1,2,4,8,16,32).  The HIP kernels are bit-exact against this order.
  * and, orthogonally, hub chunking (chunk > 0): a row with more than `chunk` neighbours
- * is cut into chunks of `chunk` neighbours; each chunk accumulates from zero (the last
- * chunk also takes the negative samples) and the chunk partials are combined by a
+ * is cut into pieces of at most `chunk` neighbours -- after every `chunk` neighbours and
+ * (orc_set_class_cut, default 8) wherever the ascending neighbour ids cross from one eighth
+ * of the id range into the next: piece_cuts below, the engine's rule of the same name;
+ * each piece accumulates from zero (the last
+ * one also takes the negative samples) and the pieces' partials are combined by a
  * `fanin`-ary tree: consecutive groups of `fanin` partials are added sequentially, level
  * by level, until one is left (fanin == 0: one sequential pass over all partials).
  * chunk == 0 is the reference's single sequential accumulation.
@@ -272,6 +275,39 @@ static float reduce_terms(float *t, uint32_t D, int order) {
 static uint32_t g_fanin = 32;
 void orc_set_fanin(uint32_t fanin) { g_fanin = fanin; }
 
+/* Where a row of more than `chunk` neighbours is cut into pieces (the engine's piece_cuts, force2vec_amd/csrc/f2v_engine.hip):
+ * after every `chunk` neighbours and -- unless switched off with orc_set_class_cut(0) -- wherever the ascending neighbour ids
+ * cross from one of g_classes equal parts of the id range [0, n) into the next.  Returns the number of pieces; cuts[0..pieces]
+ * are the offsets of the pieces' first neighbours and, last, deg (cuts has room for deg + 1 entries). */
+static uint32_t g_classes = 8;
+void orc_set_class_cut(uint32_t classes) { g_classes = classes; }
+
+static uint32_t piece_cuts(const uint32_t *nbrs, uint32_t deg, uint32_t chunk, uint32_t n, uint32_t *cuts) {
+    uint32_t np = 0;
+    if (chunk == 0 || deg <= chunk) {
+        cuts[0] = 0;
+        cuts[1] = deg;
+        return 1;
+    }
+    if (g_classes == 0 || n == 0) {
+        for (uint32_t b = 0; b < deg; b += chunk) cuts[np++] = b;
+        cuts[np] = deg;
+        return np;
+    }
+    uint32_t start = 0, cls = (uint32_t)(((uint64_t)nbrs[0] * g_classes) / n);
+    cuts[np++] = 0;
+    for (uint32_t e = 1; e < deg; e++) {
+        uint32_t ce = (uint32_t)(((uint64_t)nbrs[e] * g_classes) / n);
+        if (ce != cls || e - start == chunk) {
+            cuts[np++] = e;
+            start = e;
+            cls = ce;
+        }
+    }
+    cuts[np] = deg;
+    return np;
+}
+
 /* parts: n partial vectors of D floats, contiguous; combined in place into parts[0..D). */
 static void combine_partials(float *parts, uint32_t n, uint32_t D) {
     uint32_t G = g_fanin ? g_fanin : n;
@@ -318,15 +354,15 @@ static void tdist_accumulate(const float *xi, const float *xj, uint32_t D, float
 }
 
 /* option 5 row: sample/algorithms.cpp:588-639 */
-static void row_tdist(const float *X, uint32_t D, uint32_t i, const uint32_t *nbrs, uint32_t deg,
+static void row_tdist(const float *X, uint32_t D, uint32_t n, uint32_t i, const uint32_t *nbrs, uint32_t deg,
                       const float *const *S, uint32_t ns, float lr, int order, uint32_t chunk,
                       float *out) {
     const float *xi = X + (size_t)i * D;
-    uint32_t nchunks = (chunk > 0 && deg > chunk) ? (deg + chunk - 1) / chunk : 1;
+    uint32_t *cuts = (uint32_t *)malloc(((size_t)deg + 2) * sizeof(uint32_t));
+    uint32_t nchunks = piece_cuts(nbrs, deg, chunk, n, cuts);
     float *parts = (float *)malloc((size_t)nchunks * D * sizeof(float));
     for (uint32_t c = 0; c < nchunks; c++) {
-        uint32_t lo = (nchunks == 1) ? 0 : c * chunk;
-        uint32_t hi = (nchunks == 1) ? deg : (lo + chunk < deg ? lo + chunk : deg);
+        uint32_t lo = cuts[c], hi = cuts[c + 1];
         float *P = parts + (size_t)c * D;
         for (uint32_t d = 0; d < D; d++) P[d] = 0.0f;
         for (uint32_t k = lo; k < hi; k++)
@@ -337,22 +373,23 @@ static void row_tdist(const float *X, uint32_t D, uint32_t i, const uint32_t *nb
     combine_partials(parts, nchunks, D);
     for (uint32_t d = 0; d < D; d++) out[d] = xi[d] + parts[d]; /* algorithms.cpp:636 */
     free(parts);
+    free(cuts);
 }
 
 /* options 6/7 row: sample/algorithms.cpp:833-921 (6), 1142-1193 (7).
  * The accumulator starts as a COPY of x_i (algorithms.cpp:824-831) and replaces x_i. */
-static void row_sigmoid(const float *X, uint32_t D, uint32_t i, const uint32_t *nbrs, uint32_t deg,
+static void row_sigmoid(const float *X, uint32_t D, uint32_t n, uint32_t i, const uint32_t *nbrs, uint32_t deg,
                         uint32_t graph_deg, const float *const *S, uint32_t ns, float lr,
                         const float *table, int order, uint32_t chunk, float *out) {
     const float *xi = X + (size_t)i * D;
     float t[ORC_MAXDIM];
     float degi = (float)(1.0 / (double)(graph_deg + 1u)); /* algorithms.cpp:854 */
     double c0 = (double)(lr * degi);
-    uint32_t nchunks = (chunk > 0 && deg > chunk) ? (deg + chunk - 1) / chunk : 1;
+    uint32_t *cuts = (uint32_t *)malloc(((size_t)deg + 2) * sizeof(uint32_t));
+    uint32_t nchunks = piece_cuts(nbrs, deg, chunk, n, cuts);
     float *parts = (float *)malloc((size_t)nchunks * D * sizeof(float));
     for (uint32_t c = 0; c < nchunks; c++) {
-        uint32_t lo = (nchunks == 1) ? 0 : c * chunk;
-        uint32_t hi = (nchunks == 1) ? deg : (lo + chunk < deg ? lo + chunk : deg);
+        uint32_t lo = cuts[c], hi = cuts[c + 1];
         float *P = parts + (size_t)c * D;
         /* chunk 0 starts from x_i (the reference's copy-in); later chunks from zero */
         for (uint32_t d = 0; d < D; d++) P[d] = (c == 0) ? xi[d] : 0.0f;
@@ -381,6 +418,7 @@ static void row_sigmoid(const float *X, uint32_t D, uint32_t i, const uint32_t *
     combine_partials(parts, nchunks, D);
     memcpy(out, parts, D * sizeof(float)); /* algorithms.cpp:918 */
     free(parts);
+    free(cuts);
 }
 
 /* ------------------------------------------------------------------------------------
@@ -414,11 +452,11 @@ int orc_minibatch(int option, int bs_mode, const uint32_t *rowptr, const uint32_
         uint32_t gdeg = rowptr[i + 1] - rowptr[i];
         float *out = newrows + (size_t)(i - lo) * D;
         if (option == 5)
-            row_tdist(X, D, i, colids + rowptr[i], gdeg, S, ns, lr, order, chunk, out);
+            row_tdist(X, D, n, i, colids + rowptr[i], gdeg, S, ns, lr, order, chunk, out);
         else if (option == 6)
-            row_sigmoid(X, D, i, colids + rowptr[i], gdeg, gdeg, S, ns, lr, table, order, chunk, out);
+            row_sigmoid(X, D, n, i, colids + rowptr[i], gdeg, gdeg, S, ns, lr, table, order, chunk, out);
         else if (option == 7)
-            row_sigmoid(X, D, i, walks + (size_t)i * ORC_WALKLENGTH, ORC_WALKLENGTH, gdeg, S, ns, lr,
+            row_sigmoid(X, D, n, i, walks + (size_t)i * ORC_WALKLENGTH, ORC_WALKLENGTH, gdeg, S, ns, lr,
                         table, order, 0 /* the 5 walk samples are never split */, out);
         else { free(snap); free(newrows); free((void *)S); return -2; }
     }
@@ -504,7 +542,7 @@ int orc_train(int option, int bs_mode, const uint32_t *rowptr, const uint32_t *c
 
 /* New embedding of ONE row given the pre-batch X and explicit sample ids (full-size
  * sampled-row checks: the test downloads X before a step and compares chosen rows). */
-int orc_row(int option, const uint32_t *rowptr, const uint32_t *colids, uint32_t D, const float *X,
+int orc_row(int option, const uint32_t *rowptr, const uint32_t *colids, uint32_t n, uint32_t D, const float *X,
             uint32_t i, const uint32_t *sample_ids, uint32_t ns, float lr, const uint32_t *walks,
             int order, uint32_t chunk, float *out) {
     if (D > ORC_MAXDIM) return -1;
@@ -514,11 +552,11 @@ int orc_row(int option, const uint32_t *rowptr, const uint32_t *colids, uint32_t
     uint32_t gdeg = rowptr[i + 1] - rowptr[i];
     int rc = 0;
     if (option == 5)
-        row_tdist(X, D, i, colids + rowptr[i], gdeg, S, ns, lr, order, chunk, out);
+        row_tdist(X, D, n, i, colids + rowptr[i], gdeg, S, ns, lr, order, chunk, out);
     else if (option == 6)
-        row_sigmoid(X, D, i, colids + rowptr[i], gdeg, gdeg, S, ns, lr, table, order, chunk, out);
+        row_sigmoid(X, D, n, i, colids + rowptr[i], gdeg, gdeg, S, ns, lr, table, order, chunk, out);
     else if (option == 7)
-        row_sigmoid(X, D, i, walks + (size_t)i * ORC_WALKLENGTH, ORC_WALKLENGTH, gdeg, S, ns, lr, table,
+        row_sigmoid(X, D, n, i, walks + (size_t)i * ORC_WALKLENGTH, ORC_WALKLENGTH, gdeg, S, ns, lr, table,
                     order, 0, out);
     else
         rc = -2;

@@ -58,7 +58,8 @@ def lib():
                                 C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_int,
                                 C.c_uint32, C.c_int]
         L.orc_row.restype = C.c_int
-        L.orc_row.argtypes = [C.c_int, u32p, u32p, C.c_uint32, f32p, C.c_uint32, u32p, C.c_uint32,
+        L.orc_set_class_cut.argtypes = [C.c_uint32]
+        L.orc_row.argtypes = [C.c_int, u32p, u32p, C.c_uint32, C.c_uint32, f32p, C.c_uint32, u32p, C.c_uint32,
                               C.c_float, u32p, C.c_int, C.c_uint32, f32p]
         L.orc_write_embd.restype = C.c_int
         L.orc_write_embd.argtypes = [C.c_char_p, f32p, C.c_uint32, C.c_uint32]
@@ -141,6 +142,12 @@ def set_fanin(fanin=32):
     lib().orc_set_fanin(fanin)
 
 
+def set_class_cut(classes=8):
+    """Pieces of a split row also end where its neighbour ids cross into the next of `classes` equal id ranges (the engine's
+    "class_cut", default on = 8); 0 = every `chunk` neighbours only."""
+    lib().orc_set_class_cut(classes)
+
+
 def minibatch(option, rowptr, colids, X, lo, hi, sample_ids, ns, lr, bs_mode=0, walks=None,
               order=ORDER_TREE, chunk=0, row_lo=None, row_hi=None):
     """Update rows [row_lo,row_hi) of minibatch [lo,hi) of X in place."""
@@ -185,7 +192,7 @@ def row(option, rowptr, colids, X, i, sample_ids, lr, walks=None, order=ORDER_TR
     n, d = X.shape
     sample_ids = np.ascontiguousarray(sample_ids, dtype=np.uint32)
     out = np.empty(d, dtype=np.float32)
-    rc = lib().orc_row(option, _u32(rowptr), _u32(colids), d, _f32(X), i, _u32(sample_ids),
+    rc = lib().orc_row(option, _u32(rowptr), _u32(colids), n, d, _f32(X), i, _u32(sample_ids),
                        len(sample_ids), lr, _u32(walks), order, chunk, _f32(out))
     if rc != 0:
         raise RuntimeError("orc_row -> %d" % rc)

@@ -212,6 +212,33 @@ def test_combine_tree_give_up_is_safe_reported_at_once_and_recoverable(F):
         eng.close()
 
 
+@pytest.mark.parametrize("option,dim", [(5, 128), (6, 64)])
+def test_class_cut_rule_matches_the_oracle_both_ways(F, option, dim):
+    """ "class_cut" (default on): the pieces of a split row also end where its ascending neighbour ids cross into the next
+    eighth of the id range -- part of the summation order, so the oracle restates it (piece_cuts); with the rule switched
+    off on both sides the old every-`chunk`-neighbours cut is back.  The two orders give different bits (hub rows exist)."""
+    from force2vec_amd.graph import rmat_csr
+    rowptr, colids = rmat_csr(13, 16, seed=6)
+    res = {}
+    try:
+        for cut in (1, 0):
+            eng = F.Engine(rowptr, colids, dim)
+            assert eng.get_param("class_cut") == 1
+            eng.set_param("class_cut", cut)
+            eng.set_param("hub_chunk", 24)
+            eng.srand(1)
+            eng.init_embeddings(0 if option == 5 else 1)
+            eng.train(option, 2, 2048)
+            res[cut] = eng.get_embeddings()
+            eng.close()
+            O.set_class_cut(8 if cut else 0)
+            want = O.train(option, rowptr, colids, dim, 2, 2048, order=O.ORDER_TREE, chunk=24)
+            assert np.array_equal(res[cut], want), cut
+    finally:
+        O.set_class_cut(8)
+    assert not np.array_equal(res[0], res[1])
+
+
 @pytest.mark.parametrize("option,batch", [(5, 16384), (6, 4096)])
 def test_piece_affinity_is_placement_only(F, option, batch):
     """ "piece_affinity" moves a split row's pieces to the XCD that owns their neighbours' id range (L2 locality): which
