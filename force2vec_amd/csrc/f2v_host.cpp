@@ -148,7 +148,7 @@ using namespace f2v;
 extern "C" {
 
 const char *f2v_last_error(void) { return g_err; }
-const char *f2v_version(void) { return "f2v-mi355x 0.2 (gfx950)"; }
+const char *f2v_version(void) { return "f2v-mi355x 0.3 (gfx950)"; }
 
 f2v_rng *f2v_rng_create(uint32_t seed) {
     Rand *g = new Rand();

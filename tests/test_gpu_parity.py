@@ -236,7 +236,8 @@ def test_class_cut_rule_matches_the_oracle_both_ways(F, option, dim):
             assert np.array_equal(res[cut], want), cut
     finally:
         O.set_class_cut(8)
-    assert not np.array_equal(res[0], res[1])
+    if option == 5:  # (option 6 from U[0,1) rows: every dot product exceeds 6, sigma = 1, the attractive terms vanish in any order)
+        assert not np.array_equal(res[0], res[1])
 
 
 @pytest.mark.parametrize("option,batch", [(5, 16384), (6, 4096)])
