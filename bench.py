@@ -234,6 +234,8 @@ def main():
     ap.add_argument("--verify-rows", type=int, default=32, help="N=1: sampled rows of one more minibatch checked against the CPU oracle after the timed region (0 = skip)")
     ap.add_argument("--config5-scale", type=int, default=24, help="also measure BASELINE configs[4] (RMAT of this scale, option 11) and report it under 'extra' (0 = skip)")
     ap.add_argument("--config5-batch", type=int, default=1048576)
+    ap.add_argument("--config4", type=int, default=1, help="also measure BASELINE configs[3] (com-Orkut-sized graph, option 6) and report it under 'extra' (0 = skip)")
+    ap.add_argument("--config4-batch", type=int, default=262144)
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON result: whatever libraries print there meanwhile (gloo announces its
@@ -611,36 +613,65 @@ def main():
                 failed.append("extra batches: replica differs from the single-GPU run")
     sess.close()
     del sess, eng
+    def load_orkut_like():
+        """BASELINE configs[3]'s size (com-Orkut itself is not available offline): cached like the RMAT graphs."""
+        from force2vec_amd.graph import orkut_like_csr
+        cache = "/tmp/f2v_orkut_like_seed1.npz"
+        if os.path.exists(cache):
+            try:
+                z = np.load(cache)
+                return z["rowptr"], z["colids"]
+            except Exception:
+                pass
+        t0 = time.time()
+        rp, ci = orkut_like_csr(1)
+        log("bench: generated the Orkut-sized graph: n=%d nnz=%d in %.1fs" % (len(rp) - 1, len(ci), time.time() - t0))
+        try:
+            tmp = cache + ".%d.tmp.npz" % os.getpid()
+            np.savez(tmp, rowptr=rp, colids=ci)
+            os.replace(tmp, cache)
+        except Exception:
+            pass
+        return rp, ci
+
+    def extra_config(label, load, option, batch):
+        """One more BASELINE configuration, same measurement and the same checks as the headline: a few epochs, then (N > 1) the
+        bit-for-bit replica check or (N = 1) the sampled-row oracle check."""
+        if not use_dist or rank == 0:
+            load()  # one rank generates (or finds) the cached graph, the others read the cache
+        sync_all()
+        rp, ci = load()
+        note(rank, "%s: graph ready: n=%d nnz=%d" % (label, len(rp) - 1, len(ci)))
+        sx = Session(rp, ci, option, state["exchange"] if use_dist else args.exchange)
+        kx = max(2, min(args.steps, 5))
+        opt_saved, args.option = args.option, option
+        dtx, stx, verx = measure(sx, kx, 1, batch, tune=False)
+        out = {"workload": "%s (n=%d, nnz=%d), option %d, D=%d, batch=%d" % (label, len(rp) - 1, len(ci), option, args.dim, batch),
+               "edges_per_s": len(ci) * kx / dtx, "ms_per_epoch": dtx / kx * 1e3, "epochs": kx, "hub_chunk": sx.eng.get_param("hub_chunk")}
+        if use_dist:
+            out["exchange"] = sx.state["exchange"]
+            out["replicas_bit_identical_to_1gpu_run"] = verx
+            if sx.state["note"]:
+                out["note"] = sx.state["note"]
+        else:
+            out["compulsory_GBs"] = stx["compulsory_bytes"] / stx["device_seconds"] * 1e-9
+            out["algorithmic_GBs"] = stx["algorithmic_bytes"] / stx["device_seconds"] * 1e-9
+            if args.verify_rows > 0:
+                ax = argparse.Namespace(**vars(args))
+                ax.batch = batch
+                out["verified_rows"] = verify_rows(F, sx.eng, rp, ci, ax, args.verify_rows)
+        args.option = opt_saved
+        sx.close()
+        return out
+
     if args.config5_scale > 0:
         # BASELINE configs[4]: RMAT scale-24, option 11, D = 128, minibatches of 1 M rows -- the size at which a minibatch is
-        # milliseconds of work per rank, i.e. where the strong-scaling target lives.  Same measurement, same checks.
-        if not use_dist or rank == 0:
-            load_graph(args.config5_scale, 16, 1)
-        sync_all()
-        rp5, ci5 = load_graph(args.config5_scale, 16, 1)
-        note(rank, "config 5 graph ready: n=%d nnz=%d" % (len(rp5) - 1, len(ci5)))
-        s5 = Session(rp5, ci5, 11, state["exchange"] if use_dist else args.exchange)
-        k5 = max(2, min(args.steps, 5))
-        opt_saved, args.option = args.option, 11
-        dt5, st5, ver5 = measure(s5, k5, 1, args.config5_batch, tune=False)
-        c5 = {"workload": "RMAT scale-%d (n=%d, nnz=%d), option 11, D=%d, batch=%d" % (args.config5_scale, len(rp5) - 1, len(ci5), args.dim, args.config5_batch),
-              "edges_per_s": len(ci5) * k5 / dt5, "ms_per_epoch": dt5 / k5 * 1e3, "epochs": k5, "hub_chunk": s5.eng.get_param("hub_chunk")}
-        if use_dist:
-            c5["exchange"] = s5.state["exchange"]
-            c5["replicas_bit_identical_to_1gpu_run"] = ver5
-            if s5.state["note"]:
-                c5["note"] = s5.state["note"]
-        else:
-            c5["compulsory_GBs"] = st5["compulsory_bytes"] / st5["device_seconds"] * 1e-9
-            c5["algorithmic_GBs"] = st5["algorithmic_bytes"] / st5["device_seconds"] * 1e-9
-            if args.verify_rows > 0:
-                a5 = argparse.Namespace(**vars(args))
-                a5.batch = args.config5_batch
-                c5["verified_rows"] = verify_rows(F, s5.eng, rp5, ci5, a5, args.verify_rows)
-        args.option = opt_saved
-        extra["config5_rmat%d_option11" % args.config5_scale] = c5
-        s5.close()
-        del s5
+        # milliseconds of work per rank, i.e. where the strong-scaling target lives
+        extra["config5_rmat%d_option11" % args.config5_scale] = extra_config(
+            "RMAT scale-%d" % args.config5_scale, lambda: load_graph(args.config5_scale, 16, 1), 11, args.config5_batch)
+    if args.config4:
+        # BASELINE configs[3]: com-Orkut's size (3.07 M vertices, 117 M edges; synthetic stand-in), option 6 (sigmoid)
+        extra["config4_orkut_sized_option6"] = extra_config("Orkut-sized power-law graph", load_orkut_like, 6, args.config4_batch)
     if extra:
         res["extra"] = extra
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -212,3 +212,35 @@ def test_ipc_mapping_boundary(where, tmp_path):
     for r in range(2):
         z = np.load(str(tmp_path / ("r%d.npz" % r)))
         assert np.array_equal(z["sums"], X.sum(axis=1, dtype=np.float64)) and np.array_equal(z["sample"], X[::1009])
+
+
+def test_ingest_at_config4_size(tmp_path):
+    """SURVEY 8f row 1 at BASELINE configs[3]'s size: the com-Orkut-sized graph written as a `pattern symmetric` MatrixMarket
+    text (117 M entries, ~1.9 GB: the reader slurps the file whole and cuts it into per-thread byte ranges -- offsets and
+    counters past 2^30 are what this is about) and parsed back by f2v_read_mtx must give the identical CSR; the
+    binary CSR cache round-trips it.  (Marked gpu because of its size, not because it touches the card.)"""
+    import time
+    import force2vec_amd as F
+    from force2vec_amd.graph import edges_from_csr, orkut_like_csr
+    import pyarrow as pa
+    import pyarrow.csv as pacsv
+    rowptr, colids = cached_graph("orkut_like", orkut_like_csr)
+    n = len(rowptr) - 1
+    src, dst = edges_from_csr(rowptr, colids)
+    mtx = "/tmp/f2v_test_orkut_like.mtx"
+    with open(mtx, "wb") as f:
+        f.write(b"%%MatrixMarket matrix coordinate pattern symmetric\n%d %d %d\n" % (n, n, len(src)))
+        pacsv.write_csv(pa.table({"r": pa.array(src + 1), "c": pa.array(dst + 1)}), f, pacsv.WriteOptions(include_header=False, delimiter=" "))
+    del src, dst
+    size = os.path.getsize(mtx)
+    assert size > 1_500_000_000
+    t0 = time.time()
+    rp, ci = F.read_mtx(mtx)
+    took = time.time() - t0
+    print("f2v_read_mtx: %.2f GB, %d entries in %.1f s" % (size / 1e9, len(colids) // 2, took))
+    assert np.array_equal(rp, rowptr) and np.array_equal(ci, colids)
+    F.write_csr_bin(mtx + ".f2vcsr", rp, ci)
+    rp2, ci2 = F.read_csr_bin(mtx + ".f2vcsr")
+    assert np.array_equal(rp2, rowptr) and np.array_equal(ci2, colids)
+    os.remove(mtx)
+    os.remove(mtx + ".f2vcsr")

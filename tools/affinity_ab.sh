@@ -7,7 +7,7 @@ BATCH=${1:-65536}
 O=$R/gpurun_out/affinity
 rm -rf $O && mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --no-cpu-baseline --extra-batches= --config5-scale 0 --verify-rows 0 --batch $BATCH"
+B="python3 $R/bench.py --no-cpu-baseline --extra-batches= --config5-scale 0 --config4 0 --verify-rows 0 --batch $BATCH"
 for rep in 1 2; do for a in 0 1; do
   $B --steps 30 --warmup 5 --param piece_affinity=$a 2>/dev/null | python3 -c "import json,sys; r=json.loads(sys.stdin.read()); print('affinity $a run $rep: %.4f ms/epoch  %.2f G edges/s' % (r['ms_per_step'], r['value']/1e9))" | tee -a $O/times.txt
 done; done
