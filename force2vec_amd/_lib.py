@@ -84,6 +84,7 @@ TEST_SIGNATURES = {
     "f2v_test_gather_calibration": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32]),
     "f2v_test_wave_reduce": (C.c_int, [C.c_int, f32p, C.c_uint32, C.c_uint32, f32p]),
     "f2v_test_withhold_flag": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "f2v_test_chain_nowait": (C.c_int, [C.c_void_p, C.c_int]),
 }
 
 PUSH_EXPORT_BYTES = 256  # F2V_PUSH_EXPORT_BYTES
@@ -121,9 +122,10 @@ def selftest_lib():
     """The self-test build (fault injection, look-inside hooks): a library of its own, with its own handles."""
     global _selftest
     if _selftest is None:
-        if not os.path.exists(SELFTEST_LIB_PATH):
-            raise ImportError("%s is missing: build it with `make`" % SELFTEST_LIB_PATH)
-        L = C.CDLL(SELFTEST_LIB_PATH)
+        path = os.environ.get("F2V_SELFTEST_LIBRARY", SELFTEST_LIB_PATH)  # A/B runs of two self-test builds
+        if not os.path.exists(path):
+            raise ImportError("%s is missing: build it with `make`" % path)
+        L = C.CDLL(path)
         for table in (SIGNATURES, TEST_SIGNATURES):
             for name, (res, args) in table.items():
                 fn = getattr(L, name)

@@ -57,10 +57,10 @@ struct Plan {
 
 // One launch of qstep_chain_kernel: up to 64 consecutive minibatches (f2v_kernels.hip.h, "chained minibatches")
 struct ChainPlan {
-    size_t item_off = 0, fin_off = 0, wg_off = 0, bdesc_off = 0;
+    size_t item_off = 0, fin_off = 0, wg_off = 0;
     uint32_t n_wgs = 0, n_batches = 0, n_slots = 0, n_fin = 0;
     uint32_t first_batch = 0;  // global minibatch index of its first minibatch
-    uint32_t lo = 0, hi = 0;   // rows covered
+    uint32_t lo = 0, hi = 0, last_lo = 0;   // rows covered; first row of the last minibatch
     uint64_t nnz = 0, compulsory = 0;
     uint32_t n_hubs = 0, n_chunks = 0;
 };
@@ -97,6 +97,7 @@ struct f2v_ctx {
     uint32_t *h_kerr = nullptr;  // pinned: the kernel error words as of the last completed epoch-end copy (train_impl)
 #ifdef F2V_TEST_HOOKS
     uint32_t test_withhold_slot = kNoSlot;
+    bool test_chain_nowait = false;  // timing experiment: chained launches without their row waits (results are then wrong)
 #endif
     bool merge_fin = true, capturing = false;  // all combine-tree levels in one launch (not while a hipGraph is captured)
     int cur = 0;  // d_X[cur]: current matrix; d_X[cur^1]: receives the rows updated this epoch
@@ -110,13 +111,11 @@ struct f2v_ctx {
     // chained minibatches ("chain_batches"): one launch per group of minibatches of f2v_train
     std::map<std::tuple<uint32_t, uint32_t, uint32_t>, ChainPlan> chains;  // (first minibatch, minibatches, batch size)
     std::vector<WgDesc> h_wg;
-    std::vector<BatchDesc> h_bdesc;
     WgDesc *d_wg = nullptr;
-    BatchDesc *d_bdesc = nullptr;
-    size_t d_wg_cap = 0, d_bdesc_cap = 0, d_wg_valid = 0, d_bdesc_valid = 0;
+    size_t d_wg_cap = 0, d_wg_valid = 0;
     uint32_t *d_rowflag = nullptr;  // per row: sequence number of the chained launch that last wrote it
     bool chain = true;            // "chain_batches"
-    uint32_t chain_max_batch = 512, chain_rows = 16384;  // measured on RMAT-20: chaining wins up to batch ~512 (tools/small_batch.py)
+    uint32_t chain_max_batch = 4096, chain_rows = 65536;  // measured on RMAT-20 (tools/small_batch.py, tools/chain_sweep.py)
     std::vector<Item> h_items;
     std::vector<FinItem> h_hubs;
     Item *d_items = nullptr;
@@ -130,7 +129,7 @@ struct f2v_ctx {
     int waves_per_block = 4;
     bool fast_rng = false;        // non-parity mode: device-side init and option-7 walks (counter-based RNG)
     uint64_t fast_seed = 1, fast_epoch = 0;
-    int rows_in_flight = 4;
+    int rows_in_flight = 0;  // 0: the kernels' default (4 at D = 128 and 256, 8 below)
     bool class_cut = true;         // split rows are also cut where their neighbour ids cross into the next eighth of the id range (piece_cuts)
     bool piece_affinity = true;    // hub pieces are placed on the XCD that owns their neighbours' id range (see plan_for)
     bool shared_card = false;      // a peer of the push exchange runs on the same GPU: placement goes back to same-XCD groups
@@ -181,7 +180,9 @@ int pick_vec(uint32_t D) {
 // the graph and the number of rows one launch covers (the batch, or a rank's slice of it in f2v_train_sharded).
 uint32_t auto_chunk(const f2v_ctx *c, uint32_t batch) {
     const double est = (double)std::min(batch, c->n) * ((double)c->nnz / (double)c->n) / 14000.0;
-    uint32_t ch = 8;
+    // (from 4: minibatches of up to ~2000 rows are bound by the latency of their longest item, not by throughput -- batch 256
+    // chained: 15.6 ms per epoch with 4-neighbour pieces, 18.2 with 8, 23.6 with 16)
+    uint32_t ch = 4;
     while (ch < 512 && (double)ch * 1.5 < est) ch <<= 1;
     return ch;
 }
@@ -190,8 +191,7 @@ void drop_plans(f2v_ctx *c) {
     c->plans.clear();
     c->chains.clear();
     c->h_wg.clear();
-    c->h_bdesc.clear();
-    c->d_wg_valid = c->d_bdesc_valid = 0;
+    c->d_wg_valid = 0;
     c->max_slots = 0;
     c->h_items.clear();
     c->h_hubs.clear();
@@ -265,6 +265,13 @@ uint64_t compulsory_bytes(f2v_ctx *c, uint32_t row_lo, uint32_t row_hi, bool wal
     return distinct * 4ull * c->D + (uint64_t)(row_hi - row_lo) * 4ull * c->D + nnz * 4ull + n_items * sizeof(Item);
 }
 
+// The plan cache may hold a few epochs' worth of items (one epoch: every row or piece once -- about nnz / chunk + 8 per split
+// row + n); beyond that it is dropped and rebuilt on demand (a run that alternates batch sizes).
+size_t plan_cache_limit(const f2v_ctx *c) {
+    const size_t epoch = (size_t)(c->nnz / std::max<uint32_t>(c->chunk, 1u)) + 2 * (size_t)c->n + 1024;
+    return std::max<size_t>(8 * ((size_t)c->n + 1024), 3 * epoch);
+}
+
 // Work items of one launch (rows [row_lo,row_hi), CSR neighbours or walk samples): a whole row, or
 // `chunk`-neighbour pieces of a hub row, longest first (the longest waves start first and the four quarters of a
 // wave get items of nearly equal length).  Host-side, cached per launch shape.
@@ -284,7 +291,7 @@ const Plan &plan_for(f2v_ctx *c, uint32_t row_lo, uint32_t row_hi, bool walk) {
     const auto key = std::make_tuple(row_lo, row_hi, walk ? 1 : 0);
     auto itp = c->plans.find(key);
     if (itp != c->plans.end()) return itp->second;
-    if (c->h_items.size() > 8 * ((size_t)c->n + 1024)) drop_plans(c);  // bound the cache
+    if (c->h_items.size() > plan_cache_limit(c)) drop_plans(c);  // bound the cache
     constexpr uint32_t kXcds = 8;
     const uint32_t ipb = items_per_block(c), npb = (uint32_t)c->waves_per_block;
     Plan p;
@@ -371,16 +378,18 @@ const Plan &plan_for(f2v_ctx *c, uint32_t row_lo, uint32_t row_hi, bool walk) {
         // One workgroup per class per round, longest first overall: a class's workgroup takes its own pieces as long as
         // they are at least as long as the longest whole row still waiting (whole rows may run anywhere), else whole rows.
         size_t pos[kXcds] = {}, wpos = 0;
-        for (bool more = true; more;) {
-            more = false;
-            for (uint32_t k = 0; k < kXcds; k++) {
-                for (uint32_t j = 0; j < ipb; j++) {
-                    const bool mine = pos[k] < queue[k].size(), any = wpos < whole.size();
-                    if (mine && (!any || queue[k][pos[k]].cnt >= whole[wpos].cnt)) items.push_back(queue[k][pos[k]++]);
-                    else if (any) items.push_back(whole[wpos++]);
-                    else { items.push_back(pad_item); padded = true; }
+        {
+            for (bool more = true; more;) {
+                more = false;
+                for (uint32_t k = 0; k < kXcds; k++) {
+                    for (uint32_t j = 0; j < ipb; j++) {
+                        const bool mine = pos[k] < queue[k].size(), any = wpos < whole.size();
+                        if (mine && (!any || queue[k][pos[k]].cnt >= whole[wpos].cnt)) items.push_back(queue[k][pos[k]++]);
+                        else if (any) items.push_back(whole[wpos++]);
+                        else { items.push_back(pad_item); padded = true; }
+                    }
+                    more = more || pos[k] < queue[k].size();
                 }
-                more = more || pos[k] < queue[k].size();
             }
         }
         items.insert(items.end(), whole.begin() + wpos, whole.end());
@@ -456,6 +465,7 @@ const ChainPlan &chain_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t ba
     const auto key = std::make_tuple(b0, K, batch);
     auto itp = c->chains.find(key);
     if (itp != c->chains.end()) return itp->second;
+    if (c->h_items.size() > plan_cache_limit(c)) drop_plans(c);  // bound the cache
     const uint32_t ipb = items_per_block(c), npb = (uint32_t)c->waves_per_block;
     ChainPlan p;
     p.first_batch = b0;
@@ -463,7 +473,6 @@ const ChainPlan &chain_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t ba
     p.item_off = c->h_items.size();
     p.fin_off = c->h_hubs.size();
     p.wg_off = c->h_wg.size();
-    p.bdesc_off = c->h_bdesc.size();
     p.lo = (uint32_t)std::min<uint64_t>((uint64_t)b0 * batch, c->n);
     uint32_t slots = 0;
     struct DI { Item it; uint64_t dep; };
@@ -516,14 +525,16 @@ const ChainPlan &chain_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t ba
             slots++;
             while (items.size() % ipb != 0) items.push_back(DI{pad, 0});
         }
-        BatchDesc bd{};
+        WgDesc bd{};
         bd.lo = lo;
+        p.last_lo = lo;
         bd.item_off = (uint32_t)(c->h_items.size() - p.item_off);
         bd.n_items = (uint32_t)items.size();
         bd.step_blocks = bd.n_items / ipb;
         bd.fin_off = (uint32_t)(c->h_hubs.size() - p.fin_off);
         bd.index = b0 + k;
-        for (uint32_t w = 0; w < bd.step_blocks; w++) c->h_wg.push_back(WgDesc{k, w});
+        const size_t wg_at = c->h_wg.size();  // (fin_n is known only below: the descriptors are patched then)
+        for (uint32_t w = 0; w < bd.step_blocks; w++) { bd.blk = w; c->h_wg.push_back(bd); }
         for (const DI &d : items) c->h_items.push_back(d.it);
         // the combine trees of this minibatch's split rows, level by level (fan-in groups in chunk order, as plan_for)
         uint32_t fin_n = 0;
@@ -549,10 +560,12 @@ const ChainPlan &chain_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t ba
         while (fin_n % npb != 0) { c->h_hubs.push_back(FinItem{0, 0, kFinToStage, 0}); fin_n++; }
         bd.fin_n = fin_n;
         const uint32_t node_blocks = fin_n / npb;
-        for (uint32_t w = 0; w < node_blocks; w++) c->h_wg.push_back(WgDesc{k, bd.step_blocks + w});
-        bd.n_wgs = bd.step_blocks + node_blocks;
-        c->h_bdesc.push_back(bd);
-        p.n_wgs += bd.n_wgs;
+        // (the nodes must directly follow their minibatch's items: later minibatches' items wait for the rows the roots write,
+        // and a waiter may only ever wait for a SMALLER workgroup index -- letting the nodes trail by a few minibatches, so that
+        // they poll less, was tried: it buys 3-9 % without the row waits and deadlocks with them, caught by the bounded waits)
+        for (uint32_t w = 0; w < node_blocks; w++) { bd.blk = bd.step_blocks + w; c->h_wg.push_back(bd); }
+        for (size_t w = wg_at; w < c->h_wg.size(); w++) c->h_wg[w].fin_n = fin_n;
+        p.n_wgs += bd.step_blocks + node_blocks;
         p.n_fin += fin_n;
         p.nnz += nnz;
         if (c->count_compulsory) p.compulsory += compulsory_bytes(c, lo, hi, false, nnz, bd.n_items);
@@ -567,8 +580,7 @@ int upload_plans(f2v_ctx *c) {
     const size_t need_slots = c->max_slots;
     const bool grow_items = c->h_items.size() > c->d_items_cap, grow_hubs = c->h_hubs.size() > c->d_hubs_cap;
     const bool grow_slots = need_slots > c->partial_slots;
-    if (c->h_items.size() == c->d_items_valid && c->h_hubs.size() == c->d_hubs_valid && c->h_wg.size() == c->d_wg_valid &&
-        c->h_bdesc.size() == c->d_bdesc_valid && !grow_slots)
+    if (c->h_items.size() == c->d_items_valid && c->h_hubs.size() == c->d_hubs_valid && c->h_wg.size() == c->d_wg_valid && !grow_slots)
         return F2V_OK;  // O(1) steady state
     HIPC(hipStreamSynchronize(c->stream));  // launches in flight read these buffers
     if (c->h_wg.size() > c->d_wg_cap) {
@@ -578,19 +590,9 @@ int upload_plans(f2v_ctx *c) {
         HIPC(hipMalloc((void **)&c->d_wg, c->d_wg_cap * sizeof(WgDesc)));
         c->d_wg_valid = 0;
     }
-    if (c->h_bdesc.size() > c->d_bdesc_cap) {
-        if (c->d_bdesc) (void)hipFree(c->d_bdesc);
-        c->d_bdesc = nullptr;
-        c->d_bdesc_cap = std::max<size_t>(c->h_bdesc.size() * 3 / 2, 256);
-        HIPC(hipMalloc((void **)&c->d_bdesc, c->d_bdesc_cap * sizeof(BatchDesc)));
-        c->d_bdesc_valid = 0;
-    }
     if (c->h_wg.size() > c->d_wg_valid)
         HIPC(hipMemcpy(c->d_wg + c->d_wg_valid, c->h_wg.data() + c->d_wg_valid, (c->h_wg.size() - c->d_wg_valid) * sizeof(WgDesc), hipMemcpyHostToDevice));
-    if (c->h_bdesc.size() > c->d_bdesc_valid)
-        HIPC(hipMemcpy(c->d_bdesc + c->d_bdesc_valid, c->h_bdesc.data() + c->d_bdesc_valid, (c->h_bdesc.size() - c->d_bdesc_valid) * sizeof(BatchDesc), hipMemcpyHostToDevice));
     c->d_wg_valid = c->h_wg.size();
-    c->d_bdesc_valid = c->h_bdesc.size();
     if (grow_items) {
         if (c->d_items) (void)hipFree(c->d_items);
         c->d_items = nullptr;
@@ -917,8 +919,10 @@ int launch_chain(f2v_ctx *c, int math, const ChainPlan &plan, const uint32_t *d_
 #endif
     a.rowflag = c->d_rowflag;
     a.chain_lo = plan.lo;
+#ifdef F2V_TEST_HOOKS
+    if (c->test_chain_nowait) a.chain_lo = 0xFFFFFFFFu;  // the kernel then treats no row as "written by an earlier minibatch"
+#endif
     ca.wg = c->d_wg + plan.wg_off;
-    ca.batch = c->d_bdesc + plan.bdesc_off;
     ca.ids = d_ids_epoch;
     ca.ids_stride = ids_stride;
     const uint32_t width = subwave_width(c), wpb = (uint32_t)c->waves_per_block;
@@ -929,9 +933,10 @@ int launch_chain(f2v_ctx *c, int math, const ChainPlan &plan, const uint32_t *d_
     switch (width) {
         case 32: if (o == 5) F2V_C(5, 8, 1, 8); else F2V_C(6, 8, 1, 8); break;
         case 64: if (o == 5) F2V_C(5, 16, 1, 8); else F2V_C(6, 16, 1, 8); break;
-        // 8 rows in flight per item at D = 128 too: a chained launch is bound by the latency of the dependent items, not by
-        // occupancy (batch 256: 29.6 ms per epoch against 30.3 with 4)
-        case 128: if (o == 5) F2V_C(5, 16, 2, 8); else F2V_C(6, 16, 2, 8); break;
+        case 128:
+            if (c->rows_in_flight == 8) { if (o == 5) F2V_C(5, 16, 2, 8); else F2V_C(6, 16, 2, 8); }
+            else { if (o == 5) F2V_C(5, 16, 2, 4); else F2V_C(6, 16, 2, 4); }
+            break;
         default: if (o == 5) F2V_C(5, 16, 4, 4); else F2V_C(6, 16, 4, 4); break;
     }
 #undef F2V_C
@@ -940,7 +945,7 @@ int launch_chain(f2v_ctx *c, int math, const ChainPlan &plan, const uint32_t *d_
     if (c->upd_hi == c->upd_lo) c->upd_lo = plan.lo;
     c->upd_hi = plan.hi;
     c->pending = true;
-    c->p_lo = (uint32_t)c->h_bdesc[plan.bdesc_off + plan.n_batches - 1].lo;
+    c->p_lo = plan.last_lo;
     c->p_hi = plan.hi;
     c->stats.hub_rows += plan.n_hubs;
     c->stats.hub_chunks += plan.n_chunks;
@@ -1235,7 +1240,7 @@ int f2v_destroy(f2v_handle c) {
     (void)hipSetDevice(c->device);
     (void)push_detach(c);
     void *ptrs[] = {c->d_rowptr, c->d_colids, c->d_walks, c->d_walks_alt, c->d_ids, c->d_X[0], c->d_X[1],
-                    c->d_partials, c->d_table, c->d_items, c->d_hubs, c->d_ready, c->d_kerr, c->d_wg, c->d_bdesc, c->d_rowflag, c->push.flags, c->push.d_err, c->push.d_masks, c->push.d_patch, c->push.landing_buf};
+                    c->d_partials, c->d_table, c->d_items, c->d_hubs, c->d_ready, c->d_kerr, c->d_wg, c->d_rowflag, c->push.flags, c->push.d_err, c->push.d_masks, c->push.d_patch, c->push.landing_buf};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->h_kerr) (void)hipHostFree(c->h_kerr);
@@ -1428,7 +1433,7 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
         return F2V_OK;
     }
     if (!strcmp(name, "rows_in_flight")) {
-        if (value != 4 && value != 8) return fail(F2V_EINVAL, "rows_in_flight must be 4 or 8");
+        if (value != 0 && value != 4 && value != 8) return fail(F2V_EINVAL, "rows_in_flight must be 0 (default), 4 or 8");
         c->rows_in_flight = (int)value;
         return F2V_OK;
     }
@@ -2194,6 +2199,12 @@ int f2v_push_attach(f2v_handle c, uint32_t rank, uint32_t world, const void *all
 int f2v_test_withhold_flag(f2v_handle c, uint32_t slot) {
     if (!c) return fail(F2V_EINVAL, "null handle");
     c->test_withhold_slot = slot;
+    return F2V_OK;
+}
+
+int f2v_test_chain_nowait(f2v_handle c, int on) {
+    if (!c) return fail(F2V_EINVAL, "null handle");
+    c->test_chain_nowait = on != 0;
     return F2V_OK;
 }
 

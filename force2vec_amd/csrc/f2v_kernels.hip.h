@@ -712,7 +712,9 @@ __device__ __forceinline__ void pair_update_q(const float (&xi)[NB][4], const fl
 // Chained minibatches: row j is written by an earlier minibatch of this launch -- wait until it has been announced
 // (rowflag[j] == seq, stored by its writer after the written-through row was acknowledged).  -> true: gave up (time-out, or
 // the launch is lost already); the caller then stores nothing.
-__device__ __noinline__ bool wait_row_slow(const StepArgs &a, uint32_t j) {
+// (forceinline on purpose: as a real call -- __noinline__, to keep the cold path out of the loop -- it made the whole chained
+// kernel 3x slower: 12.4 instead of 4.7 ms per epoch without a single wait taken, tools/chain_probe_variants.py)
+__device__ __forceinline__ bool wait_row_slow(const StepArgs &a, uint32_t j) {
     const uint32_t *f = a.rowflag + j;
     const unsigned long long t0 = wall_clock64();
     for (uint32_t spins = 1;; ++spins) {
@@ -975,42 +977,40 @@ __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
 //                    workgroups in index order (checked by f2v_create's dispatch probe): the lowest unfinished one can
 //                    always run; all waits are bounded by "tree_timeout_ms" all the same (err = 3: nothing is stored from
 //                    there on, the launch drains, f2v_train fails within an epoch)
-struct WgDesc {
-    uint32_t batch;  // minibatch of the launch
-    uint32_t blk;    // workgroup index inside that minibatch's grid (step items first, then tree nodes)
-};
-struct BatchDesc {
+struct WgDesc {            // one per workgroup, 32 bytes: everything it needs to know about its minibatch in ONE load
     uint32_t lo;           // first row of the minibatch
     uint32_t item_off;     // its items (offset into the launch's item array), n_items of them
     uint32_t n_items;
-    uint32_t step_blocks;  // workgroups that step items; the rest of its n_wgs run tree nodes
+    uint32_t step_blocks;  // workgroups of the minibatch that step items; the rest run tree nodes
     uint32_t fin_off, fin_n;
-    uint32_t n_wgs;
     uint32_t index;        // global minibatch index of the epoch: which sample ids
+    uint32_t blk;          // this workgroup's index inside the minibatch's grid (step items first, then tree nodes)
 };
 struct ChainArgs {
     StepArgs base;            // what all minibatches share; items / fin_items point at the launch's arrays
     const WgDesc *wg;
-    const BatchDesc *batch;
     const uint32_t *ids;      // the epoch's sample ids, `ids_stride` per minibatch
     uint32_t ids_stride;
 };
 
+// (5 waves per SIMD like the plain kernel where the registers allow it: without the bound the D = 128 instance takes 98 VGPRs, two too many)
 template <int OPT, int LPI, int NB, int U, bool FULL>
-__global__ __launch_bounds__(256) void qstep_chain_kernel(const ChainArgs c) {
-    const WgDesc wd = c.wg[blockIdx.x];
-    const BatchDesc bd = c.batch[wd.batch];
+__global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? 5 : 1) void qstep_chain_kernel(const ChainArgs c) {
+    const WgDesc bd = c.wg[blockIdx.x];
     StepArgs a = c.base;
     a.batch_lo = bd.lo;
     a.upd_rows = bd.lo - a.upd_lo;      // rows [upd_lo, this minibatch's first row) are read from the second matrix ...
     a.chain_rows = bd.lo - a.chain_lo;  // ... those from chain_lo on after waiting for their flag
+#ifdef F2V_TEST_HOOKS
+    if (a.chain_lo == 0xFFFFFFFFu) a.chain_rows = 0u;  // f2v_test_chain_nowait
+#endif
     a.sample_ids = c.ids + (size_t)bd.index * c.ids_stride;
     a.items = c.base.items + bd.item_off;
     a.n_items = bd.n_items;
     a.step_blocks = bd.step_blocks;
     a.fin_items = bd.fin_n ? c.base.fin_items + bd.fin_off : nullptr;
     a.fin_n = bd.fin_n;
-    qstep_body<OPT, LPI, NB, U, false, FULL, true>(a, wd.blk);
+    qstep_body<OPT, LPI, NB, U, false, FULL, true>(a, bd.blk);
 }
 
 // One level of the hub combine trees of a launch: every item adds up to `fanin` partial rows in

@@ -14,12 +14,12 @@ eng = F.Engine(rowptr, colids, 128)
 eng.set_param("chain_max_batch", 1 << 20)
 eng.srand(1)
 eng.init_embeddings(0)
-for batch in (256, 384, 1024):
-    for rows in (4096, 16384, 65536, 262144):
+for batch in (256, 1024, 4096):
+    for rows in (16384, 65536, 262144):
         if rows < 2 * batch:
             continue
         eng.set_param("chain_rows", rows)
-        for chunk in (8, 16, 32, 64):
+        for chunk in (4, 8, 16, 32):
             eng.set_param("hub_chunk", chunk)
             eng.train(5, 2, batch)
             best = min(eng.train(5, 3, batch) / 3 for _ in range(2))
