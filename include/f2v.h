@@ -64,9 +64,9 @@ int f2v_get_embeddings(f2v_handle h, float *x_out);
  * minibatch; every in-grid wait is bounded by "tree_timeout_ms", default 5000 -- a wait that gives up makes the
  * running f2v_train fail with F2V_ESTATE within an epoch or two, no unannounced sum is ever added, and the handle
  * falls back to 0), 0 = one launch per tree level; f2v_create selects 0 by itself when its dispatch probe does not
- * find 8 XCDs taking workgroups round robin ("xcc_count", "xcc_round_robin" answer what it saw); "chain_batches" (default 1): f2v_train runs minibatches of up to "chain_max_batch" (512) rows in groups of
- * "chain_rows" (16384) rows per launch, ordered by row-level data dependencies inside the launch instead of launch boundaries
- * (same results; batch 256 on RMAT-20: 0.60 -> 1.06 G edges/s); "class_cut" (default 1): a split row's pieces also end where its ascending neighbour ids cross
+ * find 8 XCDs taking workgroups round robin ("xcc_count", "xcc_round_robin" answer what it saw); "chain_batches" (default 1): f2v_train runs minibatches of up to "chain_max_batch" (4096) rows in groups of
+ * "chain_rows" (65536) rows per launch, ordered by row-level data dependencies inside the launch instead of launch boundaries
+ * (same results; batch 256 on RMAT-20: 0.60 -> 2.0 G edges/s); "class_cut" (default 1): a split row's pieces also end where its ascending neighbour ids cross
  * from one eighth of the id range into the next (part of the summation order, restated by the oracle; it is what makes
  * "piece_affinity" pure); "piece_affinity" (default 1): a split row's pieces run on the XCD that owns
  * the id range of their neighbours, so that each of the eight L2s caches its own eighth of the matrix (placement only:

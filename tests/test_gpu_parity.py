@@ -588,7 +588,10 @@ def test_cli_binary_cache_and_output(F, tmp_path):
     assert open(out + "karate.mtxF2VWNS16D64IT5NS5.embd", "rb").read() == first
     X = np.fromfile(out + "karate.mtxF2VWNS16D64IT5NS5.embd.bin", np.float32).reshape(-1, 64)
     rowptr, colids = O.read_mtx(mtx)
-    want = O.train(6, rowptr, colids, 64, 5, 16, order=O.ORDER_TREE, chunk=8)
+    probe = F.Engine(rowptr, colids, 64)
+    probe.set_param("hub_chunk_for_batch", 16)  # the automatic choice f2v_train makes for -batch 16
+    want = O.train(6, rowptr, colids, 64, 5, 16, order=O.ORDER_TREE, chunk=probe.get_param("hub_chunk"))
+    probe.close()
     assert np.array_equal(X, want)
 
 
