@@ -188,8 +188,10 @@ def kernel_name(args, pushing):
     w = 16
     while w < args.dim:
         w <<= 1
-    return "f2v::qstep_kernel<%d, %d, %d, %d, %s, %s>" % (5 if args.option in (5, 8, 11) else 6, min(16, w // 4), max(1, w // 64), 4 if w >= 128 else 8,
-                                                          "true" if pushing else "false", "true" if w == args.dim else "false")
+    opt, lpi, nb, u, full = 5 if args.option in (5, 8, 11) else 6, min(16, w // 4), max(1, w // 64), 4 if w >= 128 else 8, "true" if w == args.dim else "false"
+    if not pushing and args.batch <= 4096 and args.option not in (7, 10) and args.dim % 32 == 0 and (1 << args.scale) > args.batch:
+        return "f2v::qstep_chain_kernel<%d, %d, %d, %d, %s>" % (opt, lpi, nb, u, full)  # chained minibatches ("chain_max_batch")
+    return "f2v::qstep_kernel<%d, %d, %d, %d, %s, %s>" % (opt, lpi, nb, u, "true" if pushing else "false", full)
 
 
 def run_ref(O, mtx, td, option, iters, args, cores, avx512):
