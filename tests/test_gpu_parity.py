@@ -262,13 +262,14 @@ def test_piece_affinity_is_placement_only(F, option, batch):
     assert np.array_equal(res[0], want)
 
 
-@pytest.mark.parametrize("option,dim,batch,graph", [(5, 128, 256, "rmat"), (5, 128, 384, "rmat"), (6, 128, 100, "rmat"), (5, 32, 64, "rmat"), (6, 64, 1000, "rmat"),
-                                                     (5, 256, 500, "rmat"), (6, 96, 37, "cora"), (5, 128, 1, "karate"), (5, 128, 3000, "rmat")])
-def test_chained_minibatches_equal_one_launch_per_minibatch(F, option, dim, batch, graph):
+@pytest.mark.parametrize("option,dim,batch,graph,ns", [(5, 128, 256, "rmat", 5), (5, 128, 384, "rmat", 5), (6, 128, 100, "rmat", 5), (5, 32, 64, "rmat", 5),
+                                                        (6, 64, 1000, "rmat", 5), (5, 256, 500, "rmat", 5), (6, 96, 37, "cora", 5), (5, 128, 1, "karate", 5),
+                                                        (5, 128, 3000, "rmat", 5), (5, 128, 200, "rmat", 0), (6, 128, 300, "rmat", 11), (5, 64, 128, "rmat", 9)])
+def test_chained_minibatches_equal_one_launch_per_minibatch(F, option, dim, batch, graph, ns):
     """ "chain_batches": up to 64 consecutive minibatches in ONE launch, ordered by data dependencies (completion counters
     per minibatch, per-workgroup dependency masks, sample dependencies per epoch) instead of launch boundaries -- bit for
     bit the same embeddings as one launch per minibatch, epoch after epoch, ragged last minibatch included; and equal to
-    the oracle."""
+    the oracle.  ns = 0, and ns > 8 (negative samples gathered per item instead of staged in LDS: they wait for rows too)."""
     from force2vec_amd.graph import rmat_csr
     if graph == "rmat":
         rowptr, colids = rmat_csr(14, 16, seed=2)
@@ -284,8 +285,8 @@ def test_chained_minibatches_equal_one_launch_per_minibatch(F, option, dim, batc
         eng.set_param("hub_chunk", 8)
         eng.srand(1)
         eng.init_embeddings(0 if option == 5 else 1)
-        eng.train(option, 3, batch)
-        eng.train(option, 2, batch)
+        eng.train(option, 3, batch, ns)
+        eng.train(option, 2, batch, ns)
         launches.append(eng.stats()["step_launches"])
         res.append(eng.get_embeddings())
         eng.close()
@@ -293,7 +294,7 @@ def test_chained_minibatches_equal_one_launch_per_minibatch(F, option, dim, batc
     assert launches[1] == 2 * nb and launches[0] <= 2 * (-(-nb // 2))  # really chained: at least two minibatches per launch
     assert np.array_equal(res[0], res[1]) and np.isfinite(res[0]).all()
     if graph != "rmat" or batch >= 256:
-        want = O.train(option, rowptr, colids, dim, 5, batch, order=O.ORDER_TREE, chunk=8)
+        want = O.train(option, rowptr, colids, dim, 5, batch, ns=ns, order=O.ORDER_TREE, chunk=8)
         assert np.array_equal(res[0], want)
 
 
