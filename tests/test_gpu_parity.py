@@ -782,3 +782,25 @@ def test_two_ranks_ipc_preflight_children(tmp_path):
     exe = [sys.executable, os.path.join(ROOT, "tools", "ipc_preflight.py")]
     ps = [subprocess.Popen(exe + ["0", str(r), "2", str(tmp_path), str(64 << 20), "30"]) for r in range(2)]
     assert [p.wait(timeout=120) for p in ps] == [0, 0]
+
+
+def test_bench_contract_on_a_small_graph(tmp_path):
+    """bench.py end to end on a small RMAT graph: ONE JSON line on stdout carrying the contract's keys, a roofline fraction that
+    cannot exceed 1, the in-run oracle check, the chained small batches and the config-5 leg (at a small scale here)."""
+    import json
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--scale", "15", "--batch", "8192", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--extra-batches", "384,2048", "--config5-scale", "16", "--config5-batch", "16384", "--config4", "0",
+                        "--settle-ms", "5"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in res, key
+    assert res["n_gpus"] == 1 and res["steps"] == 3 and res["unit"] == "edges/s" and res["dtype"] == "f32" and res["vs_baseline"] is None
+    roof = res["roofline"]
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and 0.0 < roof["frac"] <= 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
+    assert roof["compulsory_bytes_per_launch"] <= roof["algorithmic_bytes_per_launch"] and "qstep" in roof["kernel"]
+    assert res["config"]["verified_rows"] >= 24 and "failed" not in res
+    assert set(res["extra"]) == {"batch_384", "batch_2048", "config5_rmat16_option11"} and res["extra"]["config5_rmat16_option11"]["verified_rows"] >= 24
