@@ -102,6 +102,7 @@ struct f2v_ctx {
     bool merge_fin = true, capturing = false;  // all combine-tree levels in one launch (not while a hipGraph is captured)
     int cur = 0;  // d_X[cur]: current matrix; d_X[cur^1]: receives the rows updated this epoch
     bool have_x = false, have_walks = false;
+    bool x_invalid = false;  // a lost launch left the embeddings half-updated: they must be set or initialised again
     Rand rng;
     // work-item plans (one per distinct launch: row range x neighbour source), see plan_for()
     uint32_t chunk = 64, fanin = 32;
@@ -697,6 +698,7 @@ int kernel_gave_up(f2v_ctx *c, const char *where, const uint32_t *e) {
     c->pending = false;
     c->upd_lo = c->upd_hi = 0;
     c->have_x = false;
+    c->x_invalid = true;
     return fail(F2V_ESTATE, "%s: %u combine-tree waits gave up (first: node %u of %u [first dependent %u] on slot %u, flag %u, launch %u); "
                 "the embeddings are invalid from that minibatch on (set or initialise them again); this handle now runs with \"merge_finalize\" = 0",
                 where, e[1], e[2], e[6], e[7], e[3], e[4], e[5]);
@@ -1285,6 +1287,7 @@ int f2v_init_embeddings(f2v_handle c, int kind) {
         HIPC(hipGetLastError());
         HIPC(hipStreamSynchronize(c->stream));
         c->have_x = true;
+        c->x_invalid = false;
         return F2V_OK;
     }
     HIPC(hipStreamSynchronize(c->stream));
@@ -1319,6 +1322,7 @@ int f2v_init_embeddings(f2v_handle c, int kind) {
         HIPC(hipMemcpy(c->d_X[c->cur], x.get(), total * sizeof(float), hipMemcpyHostToDevice));
     }
     c->have_x = true;
+    c->x_invalid = false;
     return F2V_OK;
 }
 
@@ -1330,12 +1334,15 @@ int f2v_set_embeddings(f2v_handle c, const float *x) {
     c->upd_lo = c->upd_hi = 0;
     HIPC(hipMemcpy(c->d_X[c->cur], x, (size_t)c->n * c->D * sizeof(float), hipMemcpyHostToDevice));
     c->have_x = true;
+    c->x_invalid = false;
     return F2V_OK;
 }
 
 int f2v_get_embeddings(f2v_handle c, float *x_out) {
     if (!c || !x_out) return fail(F2V_EINVAL, "f2v_get_embeddings: null argument");
-    if (!c->have_x) return fail(F2V_ESTATE, "f2v_get_embeddings: embeddings were never initialised");
+    if (!c->have_x)
+        return fail(F2V_ESTATE, c->x_invalid ? "f2v_get_embeddings: the embeddings are invalid since a launch gave up a bounded wait: set or initialise them again"
+                                             : "f2v_get_embeddings: embeddings were never initialised");
     HIPC(hipSetDevice(c->device));
     int rc = flush_pending(c);
     if (rc != F2V_OK) return rc;
@@ -1821,11 +1828,18 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
         d_masks = c->push.d_masks;
     }
     if (sharded) c->push.rows_pushed = c->push.rows_allgather = 0;
+    struct Events {  // destroyed on every way out of this function
+        std::vector<hipEvent_t> all;
+        int make(hipEvent_t *e, unsigned flags) {
+            HIPC(hipEventCreateWithFlags(e, flags));
+            all.push_back(*e);
+            return F2V_OK;
+        }
+        ~Events() { for (hipEvent_t e : all) (void)hipEventDestroy(e); }
+    } events;
     hipEvent_t ev0, ev1;
-    HIPC(hipEventCreate(&ev0));
-    HIPC(hipEventCreate(&ev1));
+    if ((rc = events.make(&ev0, hipEventDefault)) != F2V_OK || (rc = events.make(&ev1, hipEventDefault)) != F2V_OK) return rc;
     HIPC(hipEventRecord(ev0, c->stream));
-    std::vector<uint32_t> walks;
 #ifdef F2V_TEST_HOOKS
     // F2V_PUSH_CHAOS=<seed> (self-test build only): every rank stalls at random minibatches (different ones on every rank)
     unsigned long long chaos = 0;
@@ -1837,8 +1851,8 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
     constexpr int kErrRing = 4;
     hipEvent_t err_ev[kErrRing];
     bool err_used[kErrRing] = {};
-    for (auto &e : err_ev) HIPC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    auto free_err_ring = [&] { for (auto &e : err_ev) (void)hipEventDestroy(e); };
+    for (auto &e : err_ev)
+        if ((rc = events.make(&e, hipEventDisableTiming)) != F2V_OK) return rc;
     auto poll_errors = [&](bool wait_slot, int slot) -> const uint32_t * {  // -> the error words if some epoch gave up
         for (int k = 0; k < kErrRing; k++) {
             if (!err_used[k]) continue;
@@ -2028,16 +2042,12 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
             } else {
                 uint32_t e[16];
                 memcpy(e, bad, sizeof e);
-                free_err_ring();
-                (void)hipEventDestroy(ev0);
-                (void)hipEventDestroy(ev1);
                 char where[96];
                 snprintf(where, sizeof where, "%s (noticed after epoch %u of %u)", sharded ? "f2v_train_sharded" : "f2v_train", it + 1, iters);
                 return kernel_gave_up(c, where, e);
             }
         }
     }
-    free_err_ring();
     if (exchanging && !need_based) c->push.rows_pushed = c->push.rows_allgather;
     if ((rc = flush_pending(c)) != F2V_OK) return rc;
     if (need_based && iters > 0) {
@@ -2056,8 +2066,6 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
     HIPC(hipEventSynchronize(ev1));
     float ms = 0.f;
     HIPC(hipEventElapsedTime(&ms, ev0, ev1));
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
     c->stats.device_seconds = ms * 1e-3;
     if (seconds_out) *seconds_out = ms * 1e-3;
     if ((rc = check_kernel_err(c, sharded ? "f2v_train_sharded" : "f2v_train")) != F2V_OK) return rc;
