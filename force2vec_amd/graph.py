@@ -41,6 +41,20 @@ def write_csr_bin(path, rowptr, colids):
                                            len(rowptr) - 1, len(colids)))
 
 
+def _symmetric_csr_dedup(n, src, dst):
+    """Symmetric CSR of the undirected pairs (src, dst), duplicate pairs MERGED, neighbour ids ascending: scipy's COO -> CSR
+    conversion (linear-time bucketing + per-row sort + duplicate merge, all compiled) -- the same arrays the all-numpy path
+    (np.unique on the pair keys, then a global key sort) builds, in a fifth of the time.  No self-loops in the input."""
+    import scipy.sparse as sp
+    r = np.concatenate([src, dst])
+    c = np.concatenate([dst, src])
+    m = sp.coo_matrix((np.ones(len(r), dtype=np.int8), (r, c)), shape=(n, n)).tocsr()  # tocsr() sums (= merges) duplicates
+    del r, c
+    m.sort_indices()
+    assert m.indptr[-1] == len(m.indices) and m.indptr[-1] < 2**32
+    return m.indptr.astype(np.uint32), m.indices.astype(np.uint32)
+
+
 def csr_from_undirected_edges(n, src, dst):
     """Symmetric CSR (both directions, ascending colids) from an undirected edge list without self-loops."""
     r = np.concatenate([src, dst]).astype(np.int64)
@@ -55,9 +69,8 @@ def csr_from_undirected_edges(n, src, dst):
     return rowptr.astype(np.uint32), colids
 
 
-def rmat_edges(scale, edge_factor=16, seed=1, a=0.57, b=0.19, c=0.19):
-    """RMAT (a,b,c,d)=(0.57,0.19,0.19,0.05) edge list of 2^scale vertices, vertex ids permuted,
-    self-loops and duplicate undirected pairs removed (BASELINE.md section 3).  -> (n, src, dst) with src > dst."""
+def _rmat_pairs(scale, edge_factor, seed, a, b, c):
+    """The raw RMAT draws: n * edge_factor (src, dst) pairs over permuted vertex ids, self-loops removed, duplicates kept."""
     rng = np.random.default_rng(seed)
     n = 1 << scale
     m = n * edge_factor
@@ -68,10 +81,17 @@ def rmat_edges(scale, edge_factor=16, seed=1, a=0.57, b=0.19, c=0.19):
         u = rng.random(m)
         src = (src << 1) | (u >= ab)
         dst = (dst << 1) | (((u >= a) & (u < ab)) | (u >= abc))
+    del u
     perm = rng.permutation(n)
     src, dst = perm[src], perm[dst]
     keep = src != dst
-    src, dst = src[keep], dst[keep]
+    return n, src[keep], dst[keep]
+
+
+def rmat_edges(scale, edge_factor=16, seed=1, a=0.57, b=0.19, c=0.19):
+    """RMAT (a,b,c,d)=(0.57,0.19,0.19,0.05) edge list of 2^scale vertices, vertex ids permuted,
+    self-loops and duplicate undirected pairs removed (BASELINE.md section 3).  -> (n, src, dst) with src > dst."""
+    n, src, dst = _rmat_pairs(scale, edge_factor, seed, a, b, c)
     hi, lo = np.maximum(src, dst), np.minimum(src, dst)
     key = np.unique(hi * n + lo)
     return n, (key // n).astype(np.int64), (key % n).astype(np.int64)
@@ -80,6 +100,12 @@ def rmat_edges(scale, edge_factor=16, seed=1, a=0.57, b=0.19, c=0.19):
 def rmat_edges_n(n, m, seed=1, a=0.57, b=0.19, c=0.19):
     """The same generator for a vertex count that is not a power of two: `m` RMAT edges over 2^ceil(log2 n) ids,
     permuted, folded into [0, n) by `id mod n`, self-loops and duplicate undirected pairs removed."""
+    n, src, dst = _rmat_pairs_n(n, m, seed, a, b, c)
+    key = np.unique(np.maximum(src, dst) * n + np.minimum(src, dst))
+    return n, key // n, key % n
+
+
+def _rmat_pairs_n(n, m, seed, a, b, c):
     rng = np.random.default_rng(seed)
     scale = max(1, int(np.ceil(np.log2(n))))
     src = np.zeros(m, dtype=np.int64)
@@ -93,9 +119,7 @@ def rmat_edges_n(n, m, seed=1, a=0.57, b=0.19, c=0.19):
     perm = rng.permutation(1 << scale)
     src, dst = perm[src] % n, perm[dst] % n
     keep = src != dst
-    src, dst = src[keep], dst[keep]
-    key = np.unique(np.maximum(src, dst) * n + np.minimum(src, dst))
-    return n, key // n, key % n
+    return n, src[keep], dst[keep]
 
 
 # com-Orkut: 3 072 441 vertices, 117 185 083 undirected edges.  The file is not in the container
@@ -105,13 +129,14 @@ ORKUT_N, ORKUT_M = 3072441, 125300000
 
 
 def orkut_like_csr(seed=1):
-    n, s, d = rmat_edges_n(ORKUT_N, ORKUT_M, seed)
-    return csr_from_undirected_edges(n, s, d)
+    n, s, d = _rmat_pairs_n(ORKUT_N, ORKUT_M, seed, 0.57, 0.19, 0.19)
+    return _symmetric_csr_dedup(n, s, d)
 
 
 def rmat_csr(scale, edge_factor=16, seed=1):
-    n, s, d = rmat_edges(scale, edge_factor, seed)
-    return csr_from_undirected_edges(n, s, d)
+    """The CSR of rmat_edges' graph (tests/test_host_boundary.py checks the two paths against each other)."""
+    n, s, d = _rmat_pairs(scale, edge_factor, seed, 0.57, 0.19, 0.19)
+    return _symmetric_csr_dedup(n, s, d)
 
 
 def write_mtx_symmetric(path, n, src, dst):

@@ -262,3 +262,19 @@ def test_push_masks_name_exactly_the_ranks_that_read_a_row():
     b = push_masks(rp, ci, 8192, 8)
     del os.environ["F2V_IO_THREADS"]
     assert np.array_equal(a, b) and a.any()
+
+
+def test_fast_graph_generators_equal_the_plain_numpy_path():
+    """rmat_csr / orkut_like_csr build their CSR through scipy's compiled COO -> CSR conversion (duplicates merged there); the
+    arrays must be exactly what unique edge list + global key sort give -- the graphs every recorded number refers to."""
+    from force2vec_amd import graph as G
+    for scale, ef in ((10, 16), (14, 16), (13, 4)):
+        n, s, d = G.rmat_edges(scale, ef, 1)
+        rp, ci = G.csr_from_undirected_edges(n, s, d)
+        rp2, ci2 = G.rmat_csr(scale, ef, 1)
+        assert np.array_equal(rp, rp2) and np.array_equal(ci, ci2)
+    n, s, d = G.rmat_edges_n(3001, 40000, 1)
+    rp, ci = G.csr_from_undirected_edges(n, s, d)
+    n2, s2, d2 = G._rmat_pairs_n(3001, 40000, 1, 0.57, 0.19, 0.19)
+    rp2, ci2 = G._symmetric_csr_dedup(n2, s2, d2)
+    assert n == n2 and np.array_equal(rp, rp2) and np.array_equal(ci, ci2)
