@@ -69,19 +69,42 @@ def csr_from_undirected_edges(n, src, dst):
     return rowptr.astype(np.uint32), colids
 
 
+def _rmat_bits(levels, m, seed, a, b, c):
+    """(src, dst) bit strings of `m` RMAT edges over `levels` levels, drawn exactly as the serial loop
+        rng = default_rng(seed); for level: u = rng.random(m); src = src << 1 | (u >= a+b); dst = dst << 1 | (a <= u < a+b or u >= a+b+c)
+    draws them -- level-major, one 64-bit draw per value -- but by edge CHUNKS in parallel threads: PCG64 can jump, so the chunk
+    [s, e) of level l starts l*m + s draws into the stream.  -> src, dst, and the generator as the serial loop leaves it."""
+    from concurrent.futures import ThreadPoolExecutor
+    import os
+    src = np.empty(m, dtype=np.int64)
+    dst = np.empty(m, dtype=np.int64)
+    ab, abc = a + b, a + b + c
+    chunk = 1 << 22
+
+    def work(s0):
+        e0 = min(s0 + chunk, m)
+        sv = np.zeros(e0 - s0, dtype=np.int64)
+        dv = np.zeros(e0 - s0, dtype=np.int64)
+        for level in range(levels):
+            bg = np.random.PCG64(seed)
+            bg.advance(level * m + s0)
+            u = np.random.Generator(bg).random(e0 - s0)
+            sv = (sv << 1) | (u >= ab)
+            dv = (dv << 1) | (((u >= a) & (u < ab)) | (u >= abc))
+        src[s0:e0] = sv
+        dst[s0:e0] = dv
+
+    with ThreadPoolExecutor(max_workers=max(1, min(16, os.cpu_count() or 1))) as pool:
+        list(pool.map(work, range(0, m, chunk)))
+    bg = np.random.PCG64(seed)
+    bg.advance(levels * m)
+    return src, dst, np.random.Generator(bg)
+
+
 def _rmat_pairs(scale, edge_factor, seed, a, b, c):
     """The raw RMAT draws: n * edge_factor (src, dst) pairs over permuted vertex ids, self-loops removed, duplicates kept."""
-    rng = np.random.default_rng(seed)
     n = 1 << scale
-    m = n * edge_factor
-    src = np.zeros(m, dtype=np.int64)
-    dst = np.zeros(m, dtype=np.int64)
-    ab, abc = a + b, a + b + c
-    for _ in range(scale):
-        u = rng.random(m)
-        src = (src << 1) | (u >= ab)
-        dst = (dst << 1) | (((u >= a) & (u < ab)) | (u >= abc))
-    del u
+    src, dst, rng = _rmat_bits(scale, n * edge_factor, seed, a, b, c)
     perm = rng.permutation(n)
     src, dst = perm[src], perm[dst]
     keep = src != dst
@@ -106,16 +129,8 @@ def rmat_edges_n(n, m, seed=1, a=0.57, b=0.19, c=0.19):
 
 
 def _rmat_pairs_n(n, m, seed, a, b, c):
-    rng = np.random.default_rng(seed)
     scale = max(1, int(np.ceil(np.log2(n))))
-    src = np.zeros(m, dtype=np.int64)
-    dst = np.zeros(m, dtype=np.int64)
-    ab, abc = a + b, a + b + c
-    for _ in range(scale):
-        u = rng.random(m)
-        src = (src << 1) | (u >= ab)
-        dst = (dst << 1) | (((u >= a) & (u < ab)) | (u >= abc))
-    del u
+    src, dst, rng = _rmat_bits(scale, m, seed, a, b, c)
     perm = rng.permutation(1 << scale)
     src, dst = perm[src] % n, perm[dst] % n
     keep = src != dst
