@@ -352,6 +352,27 @@ def test_edge_case_graphs_and_shapes(F, gname, option, dim, batch, ns, bs):
     eng.close()
 
 
+@pytest.mark.parametrize("gname", sorted(EDGE_GRAPHS))
+@pytest.mark.parametrize("option,dim,batch", [(5, 128, 1), (5, 64, 3), (6, 128, 2), (6, 32, 7)])
+def test_edge_case_graphs_through_chained_training(F, gname, option, dim, batch):
+    """The degenerate graphs again, through f2v_train with chained minibatches (self-loops: a row that is its own neighbour
+    inside its own minibatch; duplicates; a star whose hub every later minibatch waits for; a directed chain where every
+    minibatch reads the previous one; isolated vertices) -- against the oracle's f2v_train restatement."""
+    n, edges = EDGE_GRAPHS[gname]
+    rowptr, colids = _csr(n, edges)
+    eng = F.Engine(rowptr, colids, dim)
+    eng.set_param("hub_chunk", 4)
+    eng.srand(1)
+    eng.init_embeddings(0 if option == 5 else 1)
+    eng.train(option, 4, batch)
+    chained = eng.stats()["step_launches"] < 4 * -(-n // batch)
+    got = eng.get_embeddings()
+    eng.close()
+    assert chained == (n > batch)
+    want = O.train(option, rowptr, colids, dim, 4, batch, order=O.ORDER_TREE, chunk=4)
+    assert np.array_equal(got, want), float(np.nanmax(np.abs(got - want)))
+
+
 def test_sharded_rows_and_stage_exchange(F):
     """The multi-GPU unit: two engines each compute half of every minibatch and exchange staged rows."""
     n, dim, batch = 260, 128, 100
