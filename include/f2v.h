@@ -71,7 +71,7 @@ int f2v_get_embeddings(f2v_handle h, float *x_out);
  * "piece_affinity" pure); "piece_affinity" (default 1): a split row's pieces run on the XCD that owns
  * the id range of their neighbours, so that each of the eight L2s caches its own eighth of the matrix (placement only:
  * results do not change; ranks of a push exchange that share one GPU switch it off by themselves); "quarter_wave": 0 selects the one-item-per-wavefront
- * kernel for every D; "waves_per_block"; "rows_in_flight" (4|8); "use_graph" = 1 makes f2v_train replay a
+ * kernel for every D; "waves_per_block"; "rows_in_flight" (0 = the kernels' default | 4 | 8); "use_graph" = 1 makes f2v_train replay a
  * captured hipGraph per epoch instead of launching eagerly (same results; measured no faster); "count_compulsory" = 1
  * makes new launch plans count their compulsory bytes (f2v_stats.compulsory_bytes).
  * Sharded runs: "push_fused" (default 1: the step kernels push their rows themselves, 0: a kernel behind
