@@ -664,6 +664,28 @@ def test_rmat20_full_size_properties(F):
     eng.close()
 
 
+@pytest.mark.parametrize("option,batch", [(5, 384), (6, 4096), (5, 1000)])
+def test_rmat20_chained_minibatches_full_size(F, option, batch):
+    """Chained minibatches at the benchmark's size (RMAT scale-20, 1 M vertices, hubs of 64 k neighbours, ~170 minibatches per
+    launch at the reference's default batch 384): three epochs give the same bits as one launch per minibatch -- every row of
+    the 512-MB matrix compared -- and a second chained engine the same again (no dependence on timing)."""
+    from force2vec_amd.graph import rmat_csr
+    rowptr, colids = rmat_csr(20, 16, seed=1)
+    res = []
+    for chain in (1, 0, 1):
+        eng = F.Engine(rowptr, colids, 128)
+        eng.set_param("chain_batches", chain)
+        eng.srand(1)
+        eng.init_embeddings(0 if option == 5 else 1)
+        eng.train(option, 3, batch)
+        res.append(eng.get_embeddings())
+        st = eng.stats()
+        eng.close()
+        nb = -(-(len(rowptr) - 1) // batch)
+        assert (st["step_launches"] < 3 * nb // 8) == bool(chain)
+    assert np.array_equal(res[0], res[1]) and np.array_equal(res[0], res[2]) and np.isfinite(res[0]).all()
+
+
 def test_full_size_sampled_rows(F):
     """RMAT scale-16 (65 536 vertices, ~1 M nnz, hubs of thousands of neighbours) at D = 128: one
     epoch in 4 minibatches, checked on sampled rows (hubs included) against the oracle's row
