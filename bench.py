@@ -560,7 +560,7 @@ def main():
         kname = kernel_name(args, use_dist and world > 1 and state["exchange"] == "push" and eng.get_param("push_fused"))
         ach = comp / t_launch * 1e-9
         roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                "kernel": kname, "compulsory_bytes_per_launch": comp, "avg_launch_us": t_launch * 1e6, "launches": st["step_launches"],
+                "kernel": kname, "compulsory_bytes": comp, "compulsory_bytes_per_launch": comp, "avg_launch_us": t_launch * 1e6, "launches": st["step_launches"],
                 "definition": "achieved = compulsory bytes per launch (distinct embedding rows read + rows written + neighbour ids + work items, "
                               "counted by the engine) / average launch time; frac <= 1 by construction",
                 # SURVEY 8d's count charges EVERY neighbour row to HBM: a rate of useful bytes delivered to the CUs, served by L2 + Infinity Cache + HBM together
