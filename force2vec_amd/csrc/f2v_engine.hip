@@ -110,7 +110,7 @@ struct f2v_ctx {
     bool use_quarter = true;  // sub-wave kernel when D is a multiple of 4 up to 256
     std::map<std::tuple<uint32_t, uint32_t, int>, Plan> plans;
     // chained minibatches ("chain_batches"): one launch per group of minibatches of f2v_train
-    std::map<std::tuple<uint32_t, uint32_t, uint32_t>, ChainPlan> chains;  // (first minibatch, minibatches, batch size)
+    std::map<std::tuple<uint32_t, uint32_t, uint32_t, int>, ChainPlan> chains;  // (first minibatch, minibatches, batch size, walk samples instead of CSR neighbours)
     std::vector<WgDesc> h_wg;
     WgDesc *d_wg = nullptr;
     size_t d_wg_cap = 0, d_wg_valid = 0;
@@ -454,7 +454,9 @@ uint32_t chain_len(const f2v_ctx *c, uint32_t batch) {
 
 bool chain_usable(const f2v_ctx *c, int math, uint32_t batch, int bs_mode, bool sharded) {
     const uint32_t nb = (uint32_t)(((uint64_t)c->n + batch - 1) / batch);
-    return c->chain && !sharded && !bs_mode && math != 7 && c->merge_fin && c->xcc_round_robin && !c->capturing && !c->use_graph &&
+    (void)bs_mode;  // -bs 1 chains too: its per-row sample windows are gathered per item, and those gathers wait for rows like any other
+    (void)math;     // option 7 chains too: its five walk samples per row are gathered (and waited for) like CSR neighbours
+    return c->chain && !sharded && c->merge_fin && c->xcc_round_robin && !c->capturing && !c->use_graph &&
            subwave_width(c) != 0 && c->D % 32u == 0u && batch <= c->chain_max_batch && nb >= 2 && chain_len(c, batch) >= 2;
 }
 
@@ -462,8 +464,8 @@ bool chain_usable(const f2v_ctx *c, int math, uint32_t batch, int bs_mode, bool 
 // lie outside the launch's earlier minibatches first: their workgroups never wait), then its combine-tree nodes; a
 // descriptor per workgroup with the minibatches it has to wait for.  Same pieces, same fan-in, same slots-in-chunk-order as
 // plan_for: the summation order -- and with it every bit of the result -- does not depend on how minibatches are launched.
-const ChainPlan &chain_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t batch) {
-    const auto key = std::make_tuple(b0, K, batch);
+const ChainPlan &chain_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t batch, bool walk) {
+    const auto key = std::make_tuple(b0, K, batch, walk ? 1 : 0);
     auto itp = c->chains.find(key);
     if (itp != c->chains.end()) return itp->second;
     if (c->h_items.size() > plan_cache_limit(c)) drop_plans(c);  // bound the cache
@@ -497,6 +499,11 @@ const ChainPlan &chain_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t ba
             return m;
         };
         for (uint32_t i = lo; i < hi; i++) {
+            if (walk) {  // option 7: the row's five walk samples of the epoch (they change every epoch: no ordering hint)
+                items.push_back(DI{Item{i, i * (uint32_t)kWalkLength, (uint32_t)kWalkLength, kItemFirst | kItemLast}, 0});
+                nnz += kWalkLength;
+                continue;
+            }
             const uint32_t rp = c->rowptr[i], deg = c->rowptr[i + 1] - rp;
             nnz += deg;
             if (c->chunk != 0 && deg > c->chunk) {
@@ -569,7 +576,7 @@ const ChainPlan &chain_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t ba
         p.n_wgs += bd.step_blocks + node_blocks;
         p.n_fin += fin_n;
         p.nnz += nnz;
-        if (c->count_compulsory) p.compulsory += compulsory_bytes(c, lo, hi, false, nnz, bd.n_items);
+        if (c->count_compulsory) p.compulsory += compulsory_bytes(c, lo, hi, walk, nnz, bd.n_items);
     }
     p.n_slots = slots;
     c->max_slots = std::max<size_t>(c->max_slots, slots);
@@ -891,7 +898,7 @@ int launch_step(f2v_ctx *c, int math, uint32_t batch_lo, uint32_t batch_hi, uint
 
 // One chained launch: minibatches [plan.first_batch, +plan.n_batches) of an epoch whose sample ids (ids_stride per minibatch)
 // lie at d_ids_epoch.
-int launch_chain(f2v_ctx *c, int math, const ChainPlan &plan, const uint32_t *d_ids_epoch, uint32_t ids_stride, uint32_t ns, float lr) {
+int launch_chain(f2v_ctx *c, int math, const ChainPlan &plan, const uint32_t *d_ids_epoch, uint32_t ids_stride, uint32_t ns, float lr, int bs_mode) {
     int rc;
     if (c->upd_hi != c->upd_lo && plan.lo != c->upd_hi) {
         if ((rc = flush_pending(c)) != F2V_OK) return rc;
@@ -901,14 +908,14 @@ int launch_chain(f2v_ctx *c, int math, const ChainPlan &plan, const uint32_t *d_
     a.X = c->d_X[c->cur];
     a.Xn = c->d_X[c->cur ^ 1];
     a.rowptr = c->d_rowptr;
-    a.nbr_ids = c->d_colids;
+    a.nbr_ids = math == 7 ? c->d_walks : c->d_colids;
     a.partials = c->d_partials;
     a.items = c->d_items + plan.item_off;
     a.sm_table = c->d_table;
     a.D = c->D;
     a.upd_lo = (c->upd_hi == c->upd_lo) ? plan.lo : c->upd_lo;
     a.ns = ns;
-    a.bs_mode = 0u;
+    a.bs_mode = bs_mode ? 1u : 0u;
     a.lr = lr;
     a.fin_items = c->d_hubs + plan.fin_off;
     a.ready = c->d_ready;
@@ -1771,10 +1778,10 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
     // as that stays below 1 GiB); option 7 interleaves walk generation, so it goes epoch by epoch.
     const bool all_upfront = (math != 7 || c->fast_rng) && (per_epoch * iters * 4ull <= (1ull << 30));
     // small minibatches: groups of them in one launch (chain_plan_for), ordered by data dependencies instead of launch boundaries
-    const bool chained = all_upfront && iters > 0 && chain_usable(c, math, batch, bs_mode, sharded);
+    const bool chained = iters > 0 && chain_usable(c, math, batch, bs_mode, sharded);
     const uint32_t K = chained ? chain_len(c, batch) : 1;
     if (chained) {
-        for (uint32_t b0 = 0; b0 < nb; b0 += K) (void)chain_plan_for(c, b0, std::min(K, nb - b0), batch);
+        for (uint32_t b0 = 0; b0 < nb; b0 += K) (void)chain_plan_for(c, b0, std::min(K, nb - b0), batch, math == 7);
     } else {
         for (uint32_t b = 0; b < nb; b++) {  // all launch plans up-front: one upload, no syncs inside the timed loop
             uint32_t lo = b * batch, hi = (uint32_t)std::min<uint64_t>((uint64_t)b * batch + batch, n);
@@ -1803,15 +1810,15 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
             }
         }
     };
+    if (chained && !c->d_rowflag) {
+        HIPC(hipMalloc((void **)&c->d_rowflag, (size_t)c->n * sizeof(uint32_t)));
+        HIPC(hipMemsetAsync(c->d_rowflag, 0, (size_t)c->n * sizeof(uint32_t), c->stream));  // 0 is no launch's sequence number
+        HIPC(hipStreamSynchronize(c->stream));
+    }
     if (all_upfront) {
         ids.assign(per_epoch * iters, 0u);
         for (uint32_t it = 0; it < iters; it++) draw_epoch(ids, (size_t)it * per_epoch);
         if (!ids.empty()) HIPC(hipMemcpy(c->d_ids, ids.data(), ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        if (chained && !c->d_rowflag) {
-            HIPC(hipMalloc((void **)&c->d_rowflag, (size_t)c->n * sizeof(uint32_t)));
-            HIPC(hipMemsetAsync(c->d_rowflag, 0, (size_t)c->n * sizeof(uint32_t), c->stream));  // 0 is no launch's sequence number
-            HIPC(hipStreamSynchronize(c->stream));
-        }
     } else {
         ids.assign(per_epoch, 0u);
     }
@@ -2005,9 +2012,9 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
         }
         if (chained) {
             for (uint32_t b0 = 0; b0 < nb; b0 += K) {
-                const ChainPlan plan = chain_plan_for(c, b0, std::min(K, nb - b0), batch);
+                const ChainPlan plan = chain_plan_for(c, b0, std::min(K, nb - b0), batch, math == 7);
                 if ((rc = upload_plans(c)) != F2V_OK) return rc;  // O(1) unless the plan cache was dropped meanwhile
-                if ((rc = launch_chain(c, math, plan, d_epoch_ids, (uint32_t)stride, ns, lr)) != F2V_OK) return rc;
+                if ((rc = launch_chain(c, math, plan, d_epoch_ids, (uint32_t)stride, ns, lr, bs_mode)) != F2V_OK) return rc;
             }
         }
         for (uint32_t b = 0; b < nb && !chained; b++) {

@@ -364,6 +364,55 @@ def test_edge_case_graphs_and_shapes(F, gname, option, dim, batch, ns, bs):
     eng.close()
 
 
+@pytest.mark.parametrize("dim,batch,fast", [(128, 256, 0), (64, 100, 0), (128, 384, 1)])
+def test_chained_minibatches_option_7(F, dim, batch, fast):
+    """Option 7 (walk samples drawn per epoch by the producer thread, or on the device with fast_rng) through chained launches:
+    same bits as plain launches; in parity mode also as the oracle."""
+    _need_round_robin_dispatch(F)
+    from force2vec_amd.graph import rmat_csr
+    rowptr, colids = rmat_csr(13, 16, seed=7)
+    res = []
+    for chain in (1, 0):
+        eng = F.Engine(rowptr, colids, dim)
+        eng.set_param("chain_batches", chain)
+        eng.set_param("fast_rng", fast)
+        eng.srand(1)
+        eng.init_embeddings(1)
+        eng.train(7, 3, batch)
+        nb = -(-(len(rowptr) - 1) // batch)
+        assert (eng.stats()["step_launches"] < 3 * nb) == bool(chain)
+        res.append(eng.get_embeddings())
+        eng.close()
+    assert np.array_equal(res[0], res[1])
+    if not fast:
+        want = O.train(7, rowptr, colids, dim, 3, batch, order=O.ORDER_TREE, chunk=0)
+        assert np.array_equal(res[0], want)
+
+
+@pytest.mark.parametrize("option,dim,batch", [(5, 128, 256), (6, 64, 100), (5, 32, 700)])
+def test_chained_minibatches_with_bs_mode(F, option, dim, batch):
+    """-bs 1 (every row its own window of the minibatch's ns*BATCH sample ids) through chained launches: the per-item sample
+    gathers wait for rows of earlier minibatches like neighbour gathers do; same bits as plain launches and as the oracle."""
+    _need_round_robin_dispatch(F)
+    from force2vec_amd.graph import rmat_csr
+    rowptr, colids = rmat_csr(13, 16, seed=5)
+    res = []
+    for chain in (1, 0):
+        eng = F.Engine(rowptr, colids, dim)
+        eng.set_param("chain_batches", chain)
+        eng.set_param("hub_chunk", 8)
+        eng.srand(1)
+        eng.init_embeddings(0 if option == 5 else 1)
+        eng.train(option, 3, batch, 5, 0.02, 1)
+        nb = -(-(len(rowptr) - 1) // batch)
+        assert (eng.stats()["step_launches"] < 3 * nb) == bool(chain)
+        res.append(eng.get_embeddings())
+        eng.close()
+    assert np.array_equal(res[0], res[1])
+    want = O.train(option, rowptr, colids, dim, 3, batch, bs_mode=1, order=O.ORDER_TREE, chunk=8)
+    assert np.array_equal(res[0], want)
+
+
 @pytest.mark.parametrize("gname", sorted(EDGE_GRAPHS))
 @pytest.mark.parametrize("option,dim,batch", [(5, 128, 1), (5, 64, 3), (6, 128, 2), (6, 32, 7)])
 def test_edge_case_graphs_through_chained_training(F, gname, option, dim, batch):

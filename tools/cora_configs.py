@@ -21,4 +21,4 @@ for dim in (16, 128):
                 out.append(eng.train(option, 1200, batch))
                 eng.close()
             print("cora D=%3d option %d batch %d, 1200 epochs: %.3f s chained (%s), %.3f s one launch per minibatch"
-                  % (dim, option, batch, out[0], "D not a multiple of 32: not chained" if dim % 32 else ("host-side walks: not chained" if option == 7 else "chained"), out[1]), flush=True)
+                  % (dim, option, batch, out[0], "D not a multiple of 32: not chained" if dim % 32 else "chained", out[1]), flush=True)
