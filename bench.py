@@ -202,6 +202,35 @@ def run_ref(O, mtx, td, option, iters, args, cores, avx512):
     return out
 
 
+def self_launch(n_ranks, out):
+    """-> exit code.  One rank per GPU through torch.distributed.run on 127.0.0.1 with a free port; the child ranks are this very
+    script with the same arguments (they find WORLD_SIZE set and run the benchmark)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("bench: --gpus %d without a launcher: starting %s" % (n_ranks, " ".join(cmd[1:8])))
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for text in child.stdout:  # rank 0's JSON line is the only thing the ranks write to stdout; anything else goes to stderr
+        text = text.rstrip("\n")
+        if text.startswith("{") and text.endswith("}"):
+            line = text
+        elif text:
+            log(text)
+    rc = child.wait()
+    if line is not None:
+        print(line, file=out, flush=True)
+    elif rc == 0:
+        log("bench: the ranks ended without a result line")
+        rc = 4
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -250,8 +279,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # `python bench.py --gpus N` by itself: this process becomes the launcher.  It starts torch.distributed.run as a
+            # CHILD before anything here has touched the GPU (no exec of a process that has), passes the ranks' stderr
+            # through, relays rank 0's JSON line as its only stdout line and exits with the child's code.
+            sys.exit(self_launch(args.gpus, real_stdout))
         args.gpus = world
 
     import force2vec_amd as F

@@ -94,10 +94,17 @@ struct f2v_ctx {
     uint32_t xcc_count = 0;      // XCDs seen by the dispatch probe of f2v_create
     bool xcc_round_robin = false;  // ... and workgroup b ran on the XCD of workgroup b mod 8
     int64_t tree_timeout_ms = 5000;
+    int64_t chain_timeout_ms = 200;  // chained launches: a healthy one lasts a millisecond or two, so a lost one is noticed in milliseconds
+    // f2v_train survives a give-up ("recover"): the matrix and the rand() state as they were when the call began
+    bool recover = true;
+    float *d_snap = nullptr;
+    uint32_t recoveries = 0;
+    bool plan_overflow = false;  // a launch plan needed more than 2^28 partial-sum slots (kItemSlotMask)
     uint32_t *h_kerr = nullptr;  // pinned: the kernel error words as of the last completed epoch-end copy (train_impl)
 #ifdef F2V_TEST_HOOKS
     uint32_t test_withhold_slot = kNoSlot;
     bool test_chain_nowait = false;  // timing experiment: chained launches without their row waits (results are then wrong)
+    unsigned long long *d_stamps = nullptr;  // f2v_test_stamps: 4 wall-clock words per row (StepArgs::stamps)
 #endif
     bool merge_fin = true, capturing = false;  // all combine-tree levels in one launch (not while a hipGraph is captured)
     int cur = 0;  // d_X[cur]: current matrix; d_X[cur^1]: receives the rows updated this epoch
@@ -441,6 +448,7 @@ const Plan &plan_for(f2v_ctx *c, uint32_t row_lo, uint32_t row_hi, bool walk) {
         slots++;
     }
     p.n_slots = slots;
+    if (slots > kItemSlotMask) c->plan_overflow = true;  // the slot index would run into the item's flag bits: the caller fails the call
     if (c->count_compulsory) p.compulsory = compulsory_bytes(c, row_lo, row_hi, walk, p.nnz, p.n_items);
     c->max_slots = std::max<size_t>(c->max_slots, slots);
     return c->plans.emplace(key, p).first->second;
@@ -579,12 +587,18 @@ const ChainPlan &chain_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t ba
         if (c->count_compulsory) p.compulsory += compulsory_bytes(c, lo, hi, walk, nnz, bd.n_items);
     }
     p.n_slots = slots;
+    if (slots > kItemSlotMask) c->plan_overflow = true;
     c->max_slots = std::max<size_t>(c->max_slots, slots);
     return c->chains.emplace(key, p).first->second;
 }
 
 // Make every plan built so far resident in HBM (and the partial-sum buffer large enough).
 int upload_plans(f2v_ctx *c) {
+    if (c->plan_overflow) {
+        c->plan_overflow = false;
+        drop_plans(c);
+        return fail(F2V_EINVAL, "a launch plan needs more than 2^28 partial-sum slots: use a larger \"hub_chunk\" or fewer \"chain_rows\"");
+    }
     const size_t need_slots = c->max_slots;
     const bool grow_items = c->h_items.size() > c->d_items_cap, grow_hubs = c->h_hubs.size() > c->d_hubs_cap;
     const bool grow_slots = need_slots > c->partial_slots;
@@ -706,6 +720,11 @@ int kernel_gave_up(f2v_ctx *c, const char *where, const uint32_t *e) {
     c->upd_lo = c->upd_hi = 0;
     c->have_x = false;
     c->x_invalid = true;
+    if (e[0] == 3u)  // wait_row_slow: err[2] waiting workgroup, [3] row, [4] flag seen, [5] launch, [6] grid, [7] the minibatch's first row
+        return fail(F2V_ESTATE, "%s: a chained launch was lost: %u row waits gave up (first: workgroup %u of %u, minibatch starting at row %u, waiting for row %u: "
+                    "flag %u, launch %u); the embeddings are invalid from that launch on (set or initialise them again); this handle now runs one launch "
+                    "per minibatch and per combine-tree level (\"merge_finalize\" = 0)",
+                    where, e[1], e[2], e[6], e[7], e[3], e[4], e[5]);
     return fail(F2V_ESTATE, "%s: %u combine-tree waits gave up (first: node %u of %u [first dependent %u] on slot %u, flag %u, launch %u); "
                 "the embeddings are invalid from that minibatch on (set or initialise them again); this handle now runs with \"merge_finalize\" = 0",
                 where, e[1], e[2], e[6], e[7], e[3], e[4], e[5]);
@@ -920,7 +939,7 @@ int launch_chain(f2v_ctx *c, int math, const ChainPlan &plan, const uint32_t *d_
     a.fin_items = c->d_hubs + plan.fin_off;
     a.ready = c->d_ready;
     a.err = c->d_kerr;
-    a.timeout_ticks = tree_timeout_ticks(c);
+    a.timeout_ticks = (unsigned long long)std::min(c->tree_timeout_ms, c->chain_timeout_ms) * 100000ull;
     a.seq = ++c->launch_seq;
     if (a.seq == 0) a.seq = ++c->launch_seq;
 #ifdef F2V_TEST_HOOKS
@@ -930,6 +949,7 @@ int launch_chain(f2v_ctx *c, int math, const ChainPlan &plan, const uint32_t *d_
     a.chain_lo = plan.lo;
 #ifdef F2V_TEST_HOOKS
     if (c->test_chain_nowait) a.chain_lo = 0xFFFFFFFFu;  // the kernel then treats no row as "written by an earlier minibatch"
+    a.stamps = c->d_stamps;
 #endif
     ca.wg = c->d_wg + plan.wg_off;
     ca.ids = d_ids_epoch;
@@ -1214,6 +1234,10 @@ int f2v_create(const uint32_t *rowptr, const uint32_t *colids, uint32_t n, uint6
         const long ms = atol(e);
         if (ms > 0 && ms <= 600000) c->tree_timeout_ms = ms;
     }
+    if (const char *e = getenv("F2V_RECOVER")) c->recover = atoi(e) != 0;  // default of "recover" for new handles
+#ifdef F2V_TEST_HOOKS
+    if (const char *e = getenv("F2V_TEST_WITHHOLD_SLOT")) c->test_withhold_slot = (uint32_t)strtoul(e, nullptr, 0);  // f2v_test_withhold_flag from outside
+#endif
     {
         // Dispatch probe: the one-launch minibatch (combine-tree nodes waiting inside the step kernel's grid) counts on
         // 8 XCDs taking workgroups round robin.  Checked here, on this device as this process sees it; if it does not
@@ -1249,9 +1273,12 @@ int f2v_destroy(f2v_handle c) {
     (void)hipSetDevice(c->device);
     (void)push_detach(c);
     void *ptrs[] = {c->d_rowptr, c->d_colids, c->d_walks, c->d_walks_alt, c->d_ids, c->d_X[0], c->d_X[1],
-                    c->d_partials, c->d_table, c->d_items, c->d_hubs, c->d_ready, c->d_kerr, c->d_wg, c->d_rowflag, c->push.flags, c->push.d_err, c->push.d_masks, c->push.d_patch, c->push.landing_buf};
+                    c->d_partials, c->d_table, c->d_items, c->d_hubs, c->d_ready, c->d_kerr, c->d_wg, c->d_rowflag, c->d_snap, c->push.flags, c->push.d_err, c->push.d_masks, c->push.d_patch, c->push.landing_buf};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+#ifdef F2V_TEST_HOOKS
+    if (c->d_stamps) (void)hipFree(c->d_stamps);
+#endif
     if (c->h_kerr) (void)hipHostFree(c->h_kerr);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1483,6 +1510,15 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
         c->tree_timeout_ms = value;
         return F2V_OK;
     }
+    if (!strcmp(name, "chain_timeout_ms")) {
+        if (value < 1 || value > 600000) return fail(F2V_EINVAL, "chain_timeout_ms must be 1..600000");
+        c->chain_timeout_ms = value;
+        return F2V_OK;
+    }
+    if (!strcmp(name, "recover")) {
+        c->recover = value != 0;
+        return F2V_OK;
+    }
     if (!strcmp(name, "push_landing")) {  // takes effect at the next f2v_push_export
         c->push.force_landing = value != 0;
         return F2V_OK;
@@ -1525,6 +1561,9 @@ int f2v_get_param(f2v_handle c, const char *name, int64_t *out) {
     if (!strcmp(name, "merge_finalize")) { *out = c->merge_fin ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "tree_timeout_ms")) { *out = c->tree_timeout_ms; return F2V_OK; }
     if (!strcmp(name, "chain_batches")) { *out = c->chain ? 1 : 0; return F2V_OK; }
+    if (!strcmp(name, "chain_timeout_ms")) { *out = c->chain_timeout_ms; return F2V_OK; }
+    if (!strcmp(name, "recover")) { *out = c->recover ? 1 : 0; return F2V_OK; }
+    if (!strcmp(name, "recoveries")) { *out = c->recoveries; return F2V_OK; }
     if (!strcmp(name, "chain_max_batch")) { *out = c->chain_max_batch; return F2V_OK; }
     if (!strcmp(name, "chain_rows")) { *out = c->chain_rows; return F2V_OK; }
     if (!strcmp(name, "xcc_count")) { *out = c->xcc_count; return F2V_OK; }
@@ -1731,7 +1770,43 @@ int f2v_get_stats(f2v_handle c, f2v_stats *out) {
 int f2v_train(f2v_handle c, int option, uint32_t iters, uint32_t batch, uint32_t ns, float lr, int bs_mode,
               double *seconds_out) {
     if (!c) return fail(F2V_EINVAL, "null handle");
-    return train_impl(c, option, iters, batch, ns, lr, bs_mode, seconds_out, false);
+    // A launch whose workgroups wait for each other (combine-tree nodes inside the step kernel's grid, chained minibatches)
+    // counts on this process having the GPU to itself: another process that fills the card with ITS waiting workgroups can
+    // keep the ones everybody waits for from starting.  Every wait is bounded, and a wait that gives up must not cost the
+    // caller its embeddings: the matrix and the rand() state are kept as they were when the call began ("recover", one more
+    // matrix of HBM), and a call that loses a launch runs again from there with one launch per minibatch and per tree level
+    // -- no in-grid waits, the same bits.
+    bool snap = false;
+    Rand rng0 = c->rng;
+    const uint64_t fast_epoch0 = c->fast_epoch;
+    if (c->recover && c->merge_fin && c->have_x && iters > 0 && subwave_width(c) != 0) {
+        HIPC(hipSetDevice(c->device));
+        int rc = flush_pending(c);
+        if (rc != F2V_OK) return rc;
+        const size_t bytes = (size_t)c->n * c->D * sizeof(float);
+        if (!c->d_snap && hipMalloc((void **)&c->d_snap, bytes) != hipSuccess) {
+            (void)hipGetLastError();  // no room for it: the call runs without the net
+            c->d_snap = nullptr;
+        }
+        if (c->d_snap) {
+            HIPC(hipMemcpyAsync(c->d_snap, c->d_X[c->cur], bytes, hipMemcpyDeviceToDevice, c->stream));
+            snap = true;
+        }
+    }
+    int rc = train_impl(c, option, iters, batch, ns, lr, bs_mode, seconds_out, false);
+    if (rc == F2V_ESTATE && snap && c->x_invalid && !c->merge_fin) {
+        const std::string why = f2v_last_error();
+        HIPC(hipStreamSynchronize(c->stream));
+        HIPC(hipMemcpyAsync(c->d_X[c->cur], c->d_snap, (size_t)c->n * c->D * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        c->rng = rng0;
+        c->fast_epoch = fast_epoch0;
+        c->have_x = true;
+        c->x_invalid = false;
+        c->recoveries++;
+        rc = train_impl(c, option, iters, batch, ns, lr, bs_mode, seconds_out, false);
+        if (rc == F2V_OK) (void)fail(F2V_OK, "f2v_train recovered: the call was run again from its start with one launch per minibatch and tree level after: %s", why.c_str());
+    }
+    return rc;
 }
 
 int f2v_train_sharded(f2v_handle c, int option, uint32_t iters, uint32_t batch, uint32_t ns, float lr, int bs_mode,
@@ -2220,6 +2295,26 @@ int f2v_test_withhold_flag(f2v_handle c, uint32_t slot) {
 int f2v_test_chain_nowait(f2v_handle c, int on) {
     if (!c) return fail(F2V_EINVAL, "null handle");
     c->test_chain_nowait = on != 0;
+    return F2V_OK;
+}
+
+int f2v_test_stamps(f2v_handle c, int on, unsigned long long *out) {
+    if (!c) return fail(F2V_EINVAL, "null handle");
+    HIPC(hipSetDevice(c->device));
+    HIPC(hipStreamSynchronize(c->stream));
+    const size_t bytes = 4 * (size_t)c->n * sizeof(unsigned long long);
+    if (out) {
+        if (!c->d_stamps) return fail(F2V_ESTATE, "f2v_test_stamps: not switched on");
+        HIPC(hipMemcpy(out, c->d_stamps, bytes, hipMemcpyDeviceToHost));
+    }
+    if (on) {
+        if (!c->d_stamps) HIPC(hipMalloc((void **)&c->d_stamps, bytes));
+        HIPC(hipMemsetAsync(c->d_stamps, 0, bytes, c->stream));
+        HIPC(hipStreamSynchronize(c->stream));
+    } else if (c->d_stamps) {
+        (void)hipFree(c->d_stamps);
+        c->d_stamps = nullptr;
+    }
     return F2V_OK;
 }
 

@@ -110,6 +110,9 @@ struct StepArgs {
     uint32_t chain_lo, chain_rows;
 #ifdef F2V_TEST_HOOKS
     uint32_t test_withhold_slot;      // f2v_test_withhold_flag: the piece with this partial slot never announces (kNoSlot: none)
+    // f2v_test_stamps: per row four 100-MHz wall-clock words -- [0] its last hub piece announced, [1] its last inner tree node
+    // announced, [2] its row flag stored, [3] ~(first time a waiter that had to wait saw that flag); nullptr: off
+    unsigned long long *stamps;
 #endif
 };
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
@@ -471,6 +474,9 @@ struct FinalizeTreeArgs {
     unsigned long long timeout_ticks;
     uint32_t seq;
     uint32_t first_dep;       // items from this index on add sums produced INSIDE this launch
+#ifdef F2V_TEST_HOOKS
+    unsigned long long *stamps;
+#endif
 };
 
 template <int VEC, bool EXACT>
@@ -600,6 +606,9 @@ __device__ __forceinline__ void finalize_tree_node(const FinalizeTreeArgs &a, ui
             store_row_agent<VEC, EXACT>(f.Xn + (size_t)h.row * D, lane, D, Y);
             __builtin_amdgcn_s_waitcnt(0);  // the row is in memory before it is announced
             if (lane == 0) __hip_atomic_store(a.rowflag + h.row, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef F2V_TEST_HOOKS
+            if (a.stamps && lane == 0) a.stamps[4 * (size_t)h.row + 2] = wall_clock64();
+#endif
         } else {
             store_row<VEC, EXACT>(f.Xn + (size_t)h.row * D, lane, D, Y);
         }
@@ -611,6 +620,9 @@ __device__ __forceinline__ void finalize_tree_node(const FinalizeTreeArgs &a, ui
         store_row_agent<VEC, EXACT>(f.partials + (size_t)h.out * D, lane, D, Y);
         __builtin_amdgcn_s_waitcnt(0);  // the sum is in memory before it is announced
         if (lane == 0) __hip_atomic_store(a.ready + h.out, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef F2V_TEST_HOOKS
+        if (a.stamps && lane == 0) atomicMax(a.stamps + 4 * (size_t)h.row + 1, wall_clock64());
+#endif
     }
 }
 
@@ -719,7 +731,12 @@ __device__ __forceinline__ bool wait_row_slow(const StepArgs &a, uint32_t j) {
     const unsigned long long t0 = wall_clock64();
     for (uint32_t spins = 1;; ++spins) {
         __builtin_amdgcn_s_sleep(1);
-        if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.seq) return false;
+        if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.seq) {
+#ifdef F2V_TEST_HOOKS
+            if (a.stamps) atomicMax(a.stamps + 4 * (size_t)j + 3, ~wall_clock64());
+#endif
+            return false;
+        }
         if ((spins & 15u) != 0u) continue;
         if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return true;
         if (wall_clock64() - t0 > a.timeout_ticks) {
@@ -810,6 +827,9 @@ __device__ __forceinline__ void qstep_body(const StepArgs &a, const uint32_t blk
         ft.f.X = a.X; ft.f.partials = a.partials; ft.f.Xn = a.Xn; ft.f.items = a.fin_items; ft.f.n_items = a.fin_n; ft.f.D = D;
         ft.f.push = a.push;
         ft.ready = a.ready; ft.err = a.err; ft.timeout_ticks = a.timeout_ticks; ft.seq = a.seq; ft.first_dep = 0u; ft.rowflag = a.rowflag;
+#ifdef F2V_TEST_HOOKS
+        ft.stamps = a.stamps;
+#endif
         const uint32_t node = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blk - a.step_blocks) * wpb + (threadIdx.x >> 6)));
         finalize_tree_node<OPT, FVEC, (FULL && DP % 64u == 0u), CHAIN>(ft, node, lane);
         return;
@@ -942,6 +962,9 @@ __device__ __forceinline__ void qstep_body(const StepArgs &a, const uint32_t blk
     if constexpr (CHAIN) {
         __builtin_amdgcn_s_waitcnt(0);  // new rows are in memory before they are announced to the later minibatches of the launch
         if (active && !partial && t == 0u) __hip_atomic_store(a.rowflag + row, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef F2V_TEST_HOOKS
+        if (a.stamps && active && !partial && t == 0u) a.stamps[4 * (size_t)row + 2] = wall_clock64();
+#endif
     }
     if (a.fin_items) {
         __builtin_amdgcn_s_waitcnt(0);  // partial sums are in memory before they are announced
@@ -949,6 +972,9 @@ __device__ __forceinline__ void qstep_body(const StepArgs &a, const uint32_t blk
         if ((it.flags & kItemSlotMask) == a.test_withhold_slot) return;  // fault injection: this piece never announces its sum
 #endif
         if (active && partial && t == 0u) __hip_atomic_store(a.ready + (it.flags & kItemSlotMask), a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef F2V_TEST_HOOKS
+        if (a.stamps && active && partial && it.cnt != 0u && t == 0u) atomicMax(a.stamps + 4 * (size_t)row, wall_clock64());
+#endif
     }
 }
 

@@ -61,9 +61,15 @@ int f2v_get_embeddings(f2v_handle h, float *x_out);
  * the chunk is part of the summation order, so pin it where bits must not depend on the number of GPUs);
  * "hub_fanin": fan-in of the tree that adds a split row's partial sums (0 = one sequential pass);
  * "merge_finalize" (default 1): the trees' nodes run in the step kernel's own grid (one launch per
- * minibatch; every in-grid wait is bounded by "tree_timeout_ms", default 5000 -- a wait that gives up makes the
- * running f2v_train fail with F2V_ESTATE within an epoch or two, no unannounced sum is ever added, and the handle
- * falls back to 0), 0 = one launch per tree level; f2v_create selects 0 by itself when its dispatch probe does not
+ * minibatch; every in-grid wait is bounded by "tree_timeout_ms", default 5000, those of chained launches by
+ * "chain_timeout_ms", default 200 -- a wait that gives up stores nothing, the launch drains, the handle falls back to 0, and
+ * f2v_train repeats the call from the snapshot it took at its start; where it has none -- "recover" = 0, no room for one more
+ * matrix, f2v_train_sharded, f2v_minibatch_step -- the call fails with F2V_ESTATE within an epoch or two and the embeddings
+ * must be set again), 0 = one launch per tree level;
+ * SINGLE TENANT: launches with in-grid waits ("merge_finalize", "chain_batches") count on this process having the GPU to
+ * itself -- a second process (or a second handle of this one training at the same time) whose waiting workgroups fill the card
+ * can keep the workgroups they wait for from starting; the bounded waits and "recover" turn that into a slower, correct
+ * run ("recoveries" counts them), never into a hang or a wrong result.  Set both to 0 where the card is shared on purpose; f2v_create selects 0 by itself when its dispatch probe does not
  * find 8 XCDs taking workgroups round robin ("xcc_count", "xcc_round_robin" answer what it saw); "chain_batches" (default 1): f2v_train runs minibatches of up to "chain_max_batch" (4096) rows in groups of
  * "chain_rows" (65536) rows per launch, ordered by row-level data dependencies inside the launch instead of launch boundaries
  * (same results; batch 256 on RMAT-20: 0.60 -> 2.0 G edges/s); "class_cut" (default 1): a split row's pieces also end where its ascending neighbour ids cross
@@ -94,6 +100,10 @@ int f2v_get_param(f2v_handle h, const char *name, int64_t *value_out);
  * the embeddings stay in HBM (fetch with f2v_get_embeddings). */
 int f2v_train(f2v_handle h, int option, uint32_t iters, uint32_t batch, uint32_t ns, float lr, int bs_mode,
               double *seconds_out);
+/* (While "recover" is on -- the default -- and the handle uses in-grid waits, f2v_train keeps a copy of the matrix and of the
+ * rand() state as they were when the call began: one more N x D matrix of HBM, one device-to-device copy per call.  A call
+ * that loses a launch is run again from there with one launch per minibatch and per tree level: same bits, F2V_OK,
+ * f2v_last_error() says what happened, "recoveries" counts.) */
 
 /* One minibatch: the kgen row-kernel boundary Calc_<pre>frc_<tdist|sigmoid>_DIM<D>_VL<V>
  * (sample/kgen/genDimFrc.base:36-57) lifted to a batch, and the unit the multi-GPU driver

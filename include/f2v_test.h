@@ -29,6 +29,12 @@ int f2v_test_withhold_flag(f2v_handle h, uint32_t slot);
  * without the dependency chain. */
 int f2v_test_chain_nowait(f2v_handle h, int on);
 
+/* Where a chained launch spends its time: with `on`, chained launches record per row four words of the 100-MHz device wall
+ * clock -- [0] when its last hub piece announced its partial sum, [1] when its last inner combine-tree node did, [2] when its
+ * row flag was stored, [3] the bitwise complement of the first time a waiter that had to wait saw that flag.  `out` (4*n words,
+ * may be null) receives what has been recorded so far; the words are cleared whenever `on` is set.  tools/chain_hops.py. */
+int f2v_test_stamps(f2v_handle h, int on, unsigned long long *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -284,3 +284,23 @@ def test_rccl_in_place_all_gather_on_engine_stream(exchange, tmp_path):
     case = ("cora.mtx", 5, 3, 256, 128, 0)
     mp.spawn(_nccl_worker, args=(1, _free_port(), case, str(tmp_path), exchange), nprocs=1, join=True)
     assert np.array_equal(np.load(str(tmp_path / "r0.npy")), _single(case))
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it: bench.py starts torch.distributed.run itself as a child process
+    (before it has touched the GPU), relays rank 0's JSON line as its ONLY stdout line and returns the ranks' exit code.
+    Rehearsed here with two gloo ranks sharing the one card; on an 8-GPU node the same path runs over RCCL / xGMI."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--scale", "15", "--batch", "8192",
+                        "--steps", "2", "--warmup", "1", "--settle-ms", "0", "--config5-scale", "0", "--config4", "0", "--dist-extra-batches", ""],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 2 and res["scaling"] == "strong" and "failed" not in res
+    assert res["config"]["replicas_bit_identical_to_1gpu_run"] is True

@@ -179,6 +179,7 @@ def test_combine_tree_give_up_is_safe_reported_at_once_and_recoverable(F):
     assert eng.get_param("xcc_count") == 8 and eng.get_param("merge_finalize") == 1
     eng.set_param("hub_chunk", 8)
     eng.set_param("hub_fanin", 4)
+    eng.set_param("recover", 0)                                    # without f2v_train's own net (the next test is with it)
     O.set_fanin(4)
     try:
         want = O.train(5, rowptr, colids, dim, 3, batch, order=O.ORDER_TREE, chunk=8, X0=X0)
@@ -210,6 +211,101 @@ def test_combine_tree_give_up_is_safe_reported_at_once_and_recoverable(F):
     finally:
         O.set_fanin(32)
         eng.close()
+
+
+@pytest.mark.parametrize("option,batch,bs", [(5, 200, 0), (6, 64, 0), (5, 64, 1), (6, 200, 0)])
+def test_train_recovers_from_a_lost_launch(F, option, batch, bs):
+    """A launch whose in-grid waits give up must not cost the caller its embeddings ("recover", the default): f2v_train keeps
+    the matrix and the rand() state of its start and runs the call again with one launch per minibatch and tree level --
+    F2V_OK, "recoveries" = 1, the bits of a healthy run.  Fault injection as above (one hub piece never announces), for plain
+    one-launch minibatches (batch 200) and chained ones (batch 64 / 50), -bs 1 and option 7 included."""
+    from force2vec_amd import _lib
+    T = _lib.selftest_lib()
+    n, dim = 600, 128
+    rowptr, colids = random_graph(n, 6, seed=5, hubs=((3, 400), (500, 200)))
+    res = []
+    for fault in (False, True):
+        eng = F.Engine(rowptr, colids, dim, selftest=True)
+        if not eng.get_param("xcc_round_robin"):
+            eng.close()
+            pytest.skip("the dispatch probe did not find 8 XCDs taking workgroups round robin: no in-grid waits on this device")
+        eng.set_param("hub_chunk", 8)
+        eng.set_param("hub_fanin", 4)
+        assert eng.get_param("recover") == 1
+        if fault:
+            eng.set_param("tree_timeout_ms", 1)
+            _lib.check(T.f2v_test_withhold_flag(eng._h, 0), T)
+        eng.srand(1)
+        eng.init_embeddings(0 if option == 5 else 1)
+        eng.train(option, 40, batch, 5, 0.02, bs)
+        res.append(eng.get_embeddings())
+        assert eng.get_param("recoveries") == (1 if fault else 0)
+        assert eng.get_param("merge_finalize") == (0 if fault else 1)
+        if fault:
+            assert "recovered" in T.f2v_last_error().decode()
+            eng.train(option, 2, batch, 5, 0.02, bs)                 # the handle goes on, without in-grid waits
+            assert eng.get_param("recoveries") == 1 and np.isfinite(eng.get_embeddings()).all()
+        eng.close()
+    assert np.array_equal(res[0], res[1]) and np.isfinite(res[0]).all()
+
+
+def test_two_handles_training_at_once_share_the_card_safely(F):
+    """Launches with in-grid waits count on having the GPU to themselves (include/f2v.h, SINGLE TENANT).  Two handles of one
+    process training chained minibatches AT THE SAME TIME on two streams break that assumption on purpose: whatever the
+    dispatcher does -- both finish untouched, or waits give up (bound lowered to 20 ms here) and f2v_train repeats the call
+    from its snapshot -- both must end with the bits of a run alone on the card, never with lost state or a hang."""
+    import threading
+    from force2vec_amd.graph import rmat_csr
+    rowptr, colids = rmat_csr(15, 16, seed=3)
+    alone = F.Engine(rowptr, colids, 128)
+    alone.srand(1)
+    alone.init_embeddings(0)
+    alone.train(5, 6, 256)
+    want = alone.get_embeddings()
+    alone.close()
+    engs = [F.Engine(rowptr, colids, 128) for _ in range(2)]
+    errs = []
+
+    def work(e):
+        try:
+            e.set_param("chain_timeout_ms", 20)
+            e.srand(1)
+            e.init_embeddings(0)
+            for _ in range(3):   # several calls each, so that the two really overlap
+                e.train(5, 2, 256)
+        except Exception as ex:  # noqa: BLE001
+            errs.append(ex)
+
+    ts = [threading.Thread(target=work, args=(e,)) for e in engs]
+    [t.start() for t in ts]
+    [t.join(timeout=600) for t in ts]
+    assert not any(t.is_alive() for t in ts) and not errs, errs
+    for e in engs:
+        assert np.array_equal(e.get_embeddings(), want), "recoveries: %d" % e.get_param("recoveries")
+        e.close()
+
+
+def test_cli_survives_a_lost_launch(tmp_path):
+    """./bin/Force2Vec when a launch's in-grid waits give up (the self-test build preloaded in place of libf2v.so, one hub piece
+    never announcing, 1-ms bound): exit code 0 and the bytes of the healthy run -- through f2v_train's own snapshot, and, with
+    that switched off (F2V_RECOVER=0), through the rerun from the seed in algorithms::run."""
+    exe = os.path.join(ROOT, "bin", "Force2Vec")
+    selftest = os.path.join(ROOT, "force2vec_amd", "libf2v_selftest.so")
+    outs = {}
+    for name, env_extra in (("healthy", {}),
+                            ("snapshot", {"LD_PRELOAD": selftest, "F2V_TEST_WITHHOLD_SLOT": "0", "F2V_TREE_TIMEOUT_MS": "1"}),
+                            ("rerun", {"LD_PRELOAD": selftest, "F2V_TEST_WITHHOLD_SLOT": "0", "F2V_TREE_TIMEOUT_MS": "1", "F2V_RECOVER": "0"})):
+        out = str(tmp_path / name) + "/"
+        os.makedirs(out)
+        r = subprocess.run([exe, "-input", golden_graph_path("cora.mtx"), "-output", out, "-iter", "30", "-batch", "256", "-dim", "128", "-option", "5"],
+                           cwd=out, capture_output=True, text=True, timeout=300, env=dict(os.environ, **env_extra))
+        assert r.returncode == 0, name + ": " + r.stdout + r.stderr
+        outs[name] = open(out + "cora.mtxF2VNS256D128IT30NS5.embd", "rb").read()
+        if name == "snapshot":
+            assert "recovered" in r.stderr, r.stderr
+        if name == "rerun":
+            assert "running again from seed 1" in r.stderr, r.stderr
+    assert outs["healthy"] == outs["snapshot"] == outs["rerun"]
 
 
 @pytest.mark.parametrize("option,dim", [(5, 128), (6, 64)])

@@ -278,3 +278,22 @@ def test_fast_graph_generators_equal_the_plain_numpy_path():
     n2, s2, d2 = G._rmat_pairs_n(3001, 40000, 1, 0.57, 0.19, 0.19)
     rp2, ci2 = G._symmetric_csr_dedup(n2, s2, d2)
     assert n == n2 and np.array_equal(rp, rp2) and np.array_equal(ci, ci2)
+
+
+def test_bench_self_launch_propagates_failure():
+    """`python bench.py --gpus 2` without a launcher starts its own ranks (torch.distributed.run as a child).  Without a GPU
+    the ranks fail (F2V_ENODEV: there is no CPU fallback): the launcher must pass the non-zero exit code on and print no
+    result line."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["F2V_BENCH_QUIET"] = "1"
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the ranks would run")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--scale", "10", "--batch", "256",
+                        "--steps", "1", "--warmup", "0", "--no-preflight", "--config5-scale", "0", "--config4", "0"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0
+    assert r.stdout.strip() == "", r.stdout
+    assert "torch.distributed.run" in r.stderr
