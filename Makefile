@@ -12,7 +12,7 @@ LIB = force2vec_amd/libf2v.so
 TESTLIB = force2vec_amd/libf2v_selftest.so
 SRCS = $(CSRC)/f2v_engine.hip $(CSRC)/f2v_kernels.hip.h $(CSRC)/f2v_host.cpp $(CSRC)/f2v_internal.h include/f2v.h
 
-all: $(LIB) $(TESTLIB) bin/Force2Vec
+all: $(LIB) $(TESTLIB) bin/Force2Vec bin/Force2Vec_selftest
 
 $(LIB): $(SRCS)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/f2v_engine.hip $(CSRC)/f2v_host.cpp
@@ -24,6 +24,11 @@ bin/Force2Vec: $(CSRC)/cli_main.cpp $(CSRC)/algorithms.hpp include/f2v.h $(LIB)
 	mkdir -p bin
 	$(HIPCC) $(CXXFLAGS) -o $@ $(CSRC)/cli_main.cpp -Lforce2vec_amd -lf2v -Wl,-rpath,'$$ORIGIN/../force2vec_amd'
 
+# the same CLI over the self-test build of the library (fault injection through F2V_TEST_* environment variables: tests/ only)
+bin/Force2Vec_selftest: $(CSRC)/cli_main.cpp $(CSRC)/algorithms.hpp include/f2v.h $(TESTLIB)
+	mkdir -p bin
+	$(HIPCC) $(CXXFLAGS) -o $@ $(CSRC)/cli_main.cpp -Lforce2vec_amd -lf2v_selftest -Wl,-rpath,'$$ORIGIN/../force2vec_amd'
+
 clean:
-	rm -f $(LIB) $(TESTLIB) bin/Force2Vec
+	rm -f $(LIB) $(TESTLIB) bin/Force2Vec bin/Force2Vec_selftest
 .PHONY: all clean

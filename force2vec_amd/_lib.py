@@ -85,6 +85,7 @@ TEST_SIGNATURES = {
     "f2v_test_wave_reduce": (C.c_int, [C.c_int, f32p, C.c_uint32, C.c_uint32, f32p]),
     "f2v_test_withhold_flag": (C.c_int, [C.c_void_p, C.c_uint32]),
     "f2v_test_chain_nowait": (C.c_int, [C.c_void_p, C.c_int]),
+    "f2v_test_withhold_row": (C.c_int, [C.c_void_p, C.c_uint32]),
     "f2v_test_stamps": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]),
 }
 

@@ -65,6 +65,17 @@ struct ChainPlan {
     uint32_t n_hubs = 0, n_chunks = 0;
 };
 
+// One launch of qwide_chain_kernel: the same minibatches as workgroup PROGRAMS (f2v_kernels.hip.h, "wide form")
+struct WidePlan {
+    size_t item_off = 0, fin_off = 0, wg_off = 0, job_off = 0;
+    uint32_t n_wgs = 0, n_batches = 0, n_slots = 0;
+    uint32_t first_batch = 0;
+    uint32_t lo = 0, hi = 0, last_lo = 0;
+    uint64_t nnz = 0, compulsory = 0;
+    uint32_t n_hubs = 0, n_chunks = 0;
+    uint32_t n_helpers = 0, n_finishers = 0, n_packed = 0, n_node_wgs = 0;  // workgroups by role
+};
+
 // what a rank hands its peers (f2v_push_export): F2V_PUSH_EXPORT_BYTES bytes
 struct PushExport {
     hipIpcMemHandle_t x[2], flags;  // landing-buffer mode: x[0] is the landing buffer, x[1] unused
@@ -99,10 +110,11 @@ struct f2v_ctx {
     bool recover = true;
     float *d_snap = nullptr;
     uint32_t recoveries = 0;
+    int last_train_form = 0;  // how the last f2v_train launched: 0 one launch per minibatch, 1 chained, 2 chained in the wide form ("last_train_form")
     bool plan_overflow = false;  // a launch plan needed more than 2^28 partial-sum slots (kItemSlotMask)
     uint32_t *h_kerr = nullptr;  // pinned: the kernel error words as of the last completed epoch-end copy (train_impl)
 #ifdef F2V_TEST_HOOKS
-    uint32_t test_withhold_slot = kNoSlot;
+    uint32_t test_withhold_slot = kNoSlot, test_withhold_row = kNoSlot;
     bool test_chain_nowait = false;  // timing experiment: chained launches without their row waits (results are then wrong)
     unsigned long long *d_stamps = nullptr;  // f2v_test_stamps: 4 wall-clock words per row (StepArgs::stamps)
 #endif
@@ -121,6 +133,18 @@ struct f2v_ctx {
     std::vector<WgDesc> h_wg;
     WgDesc *d_wg = nullptr;
     size_t d_wg_cap = 0, d_wg_valid = 0;
+    // ... in the wide form ("chain_wide", the default where the fan-in allows it): workgroup programs and their jobs
+    std::map<std::tuple<uint32_t, uint32_t, uint32_t, int>, WidePlan> wides;
+    std::vector<WideDesc> h_wide;
+    std::vector<WJob> h_jobs;
+    WideDesc *d_wide = nullptr;
+    WJob *d_jobs = nullptr;
+    size_t d_wide_cap = 0, d_wide_valid = 0, d_jobs_cap = 0, d_jobs_valid = 0;
+    bool wide = true;
+    uint32_t wide_max_batch = 1024;  // larger chained minibatches are throughput-bound: they keep the HBM form (tools/wide_sweep.py)
+    uint32_t wide_phases = 2;   // phases (of 32 piece slots) a workgroup of small rows runs
+    uint32_t wide_span = 4;     // fan-in groups per helper workgroup
+    uint32_t wide_finish = 4;   // fan-in groups the finisher workgroup keeps for itself (the ones that wait longest)
     uint32_t *d_rowflag = nullptr;  // per row: sequence number of the chained launch that last wrote it
     bool chain = true;            // "chain_batches"
     uint32_t chain_max_batch = 4096, chain_rows = 65536;  // measured on RMAT-20 (tools/small_batch.py, tools/chain_sweep.py)
@@ -200,6 +224,10 @@ void drop_plans(f2v_ctx *c) {
     c->chains.clear();
     c->h_wg.clear();
     c->d_wg_valid = 0;
+    c->wides.clear();
+    c->h_wide.clear();
+    c->h_jobs.clear();
+    c->d_wide_valid = c->d_jobs_valid = 0;
     c->max_slots = 0;
     c->h_items.clear();
     c->h_hubs.clear();
@@ -592,6 +620,301 @@ const ChainPlan &chain_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t ba
     return c->chains.emplace(key, p).first->second;
 }
 
+
+// the wide form of a chained launch: jobs add at most 32 LDS slots, so the fan-in groups must fit
+bool wide_usable(const f2v_ctx *c) { return c->wide && c->fanin >= 2 && c->fanin <= 32 && c->waves_per_block == 4; }
+
+// Minibatches [b0, b0+K) as ONE launch of qwide_chain_kernel: per minibatch the helper workgroups of its multi-group rows,
+// then their finishers, then the workgroups that pack whole low-degree rows and rows of one fan-in group, then the
+// combine-tree nodes above the units of rows with more than fanin^2 pieces.  Pieces (piece_cuts), fan-in groups and the
+// order of every addition are those of plan_for / chain_plan_for: the result does not depend on which form ran.
+const WidePlan &wide_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t batch, bool walk) {
+    const auto key = std::make_tuple(b0, K, batch, walk ? 1 : 0);
+    auto itp = c->wides.find(key);
+    if (itp != c->wides.end()) return itp->second;
+    if (c->h_items.size() > plan_cache_limit(c)) drop_plans(c);
+    const uint32_t ipb = items_per_block(c);                  // lane groups per workgroup = items per round
+    const uint32_t pslots = std::max<uint32_t>(ipb, 32u);      // piece slots of a phase (PSLOTS of the kernel)
+    const uint32_t F = c->fanin;
+    WidePlan p;
+    p.first_batch = b0;
+    p.n_batches = K;
+    p.item_off = c->h_items.size();
+    p.fin_off = c->h_hubs.size();
+    p.wg_off = c->h_wide.size();
+    p.job_off = c->h_jobs.size();
+    p.lo = (uint32_t)std::min<uint64_t>((uint64_t)b0 * batch, c->n);
+    uint32_t slots = 0;  // partial sums in HBM: helpers' group sums, units' sums, upper tree levels
+
+    struct Prog {  // one workgroup: items laid out round by round (ipb per round), jobs in execution order
+        std::vector<Item> items;
+        std::vector<WJob> jobs;
+        uint32_t phases = 0;
+    };
+    struct Piece { Item it; uint64_t dep; };
+    struct Group { uint32_t first, n; uint64_t dep; };  // pieces [first, first+n) of `pieces`
+    struct Pack { uint32_t first, n; uint64_t dep; uint8_t kind; uint32_t dst, row; };  // a whole row (n = 1, direct) or a one-group unit
+    std::vector<Piece> pieces;
+    std::vector<Pack> packs;
+    std::vector<Prog> helpers, finishers, packed;
+    std::vector<uint32_t> cutbuf;
+    struct Node { uint32_t row, in_slot, n; };
+    std::vector<Node> cur, nxt;
+
+    // One phase's items: every item has been given its LDS slot (= the order in which the jobs add) when it was appended; they
+    // RUN in the order of what they wait for -- independent ones first, the ones that read the most recently written rows in
+    // the last round -- padded to whole rounds; the last round carries kItemPhaseEnd.
+    auto close_phase = [&](Prog &g, std::vector<Piece> &ph, uint32_t lo_row) {
+        if (ph.empty()) return;
+        std::stable_sort(ph.begin(), ph.end(), [](const Piece &x, const Piece &y) { return x.dep < y.dep; });
+        const size_t at = g.items.size();
+        for (const Piece &pc : ph) g.items.push_back(pc.it);
+        while ((g.items.size() - at) % ipb != 0) g.items.push_back(Item{lo_row, 0, 0, kItemIdle});
+        for (size_t k = g.items.size() - ipb; k < g.items.size(); k++) g.items[k].flags |= kItemPhaseEnd;
+        g.phases++;
+        ph.clear();
+    };
+    auto slotted = [](Piece pc, size_t slot) { pc.it.flags |= (uint32_t)slot; return pc; };
+    // the jobs of one phase as passes of up to 8
+    auto add_pass = [&](Prog &g, std::vector<WJob> &js) {
+        for (size_t k = 0; k < js.size(); k += 8) {
+            const uint8_t len = (uint8_t)std::min<size_t>(8, js.size() - k);
+            for (size_t u = 0; u < len; u++) { js[k + u].pass_len = len; g.jobs.push_back(js[k + u]); }
+        }
+        js.clear();
+    };
+
+    for (uint32_t k = 0; k < K; k++) {
+        const uint32_t lo = (uint32_t)std::min<uint64_t>((uint64_t)(b0 + k) * batch, c->n);
+        const uint32_t hi = (uint32_t)std::min<uint64_t>((uint64_t)lo + batch, c->n);
+        p.hi = hi;
+        p.last_lo = lo;
+        pieces.clear(); packs.clear(); helpers.clear(); finishers.clear(); packed.clear(); cur.clear();
+        uint64_t nnz = 0;
+        uint32_t mb_items = 0;
+        auto dep_of = [&](uint32_t from, uint32_t to) -> uint64_t {  // 1 + the LAST row of this launch's earlier minibatches among the neighbours [from,to): 0 = independent
+            uint64_t m = 0;
+            for (uint32_t e = from; e < to; e++) {
+                const uint32_t j = c->colids[e];
+                if (j >= p.lo && j < lo) m = std::max<uint64_t>(m, (uint64_t)(j - p.lo) + 1);
+            }
+            return m;
+        };
+        for (uint32_t i = lo; i < hi; i++) {
+            if (walk) {  // option 7: the row's five walk samples of the epoch
+                pieces.push_back(Piece{Item{i, i * (uint32_t)kWalkLength, (uint32_t)kWalkLength, kItemFirst | kItemLast | kItemDirect}, 0});
+                packs.push_back(Pack{(uint32_t)pieces.size() - 1, 1, 0, kJobRow, 0, i});
+                nnz += kWalkLength;
+                continue;
+            }
+            const uint32_t rp = c->rowptr[i], deg = c->rowptr[i + 1] - rp;
+            nnz += deg;
+            if (!(c->chunk != 0 && deg > c->chunk)) {
+                pieces.push_back(Piece{Item{i, rp, deg, kItemFirst | kItemLast | kItemDirect}, dep_of(rp, rp + deg)});
+                packs.push_back(Pack{(uint32_t)pieces.size() - 1, 1, pieces.back().dep, kJobRow, 0, i});
+                continue;
+            }
+            cutbuf.clear();
+            piece_cuts(c, i, cutbuf);
+            const uint32_t P = (uint32_t)cutbuf.size() - 1;
+            p.n_hubs++;
+            p.n_chunks += P;
+            const uint32_t first_piece = (uint32_t)pieces.size();
+            for (uint32_t q = 0; q < P; q++) {
+                const uint32_t b = cutbuf[q], e = cutbuf[q + 1];
+                pieces.push_back(Piece{Item{i, rp + b, e - b, (q == 0 ? kItemFirst : 0u) | (q == P - 1 ? kItemLast : 0u)}, dep_of(rp + b, rp + e)});
+            }
+            // units of F*F pieces (F groups of F): one unit is the whole row unless the row has more pieces than that
+            const uint32_t per_unit = F * F;
+            const uint32_t n_units = (P + per_unit - 1) / per_unit;
+            uint32_t unit_base = 0;
+            if (n_units > 1) {
+                unit_base = slots;
+                slots += n_units;
+                cur.push_back(Node{i, unit_base, n_units});
+            }
+            for (uint32_t u = 0; u < n_units; u++) {
+                const uint32_t u0 = u * per_unit, u1 = std::min(P, u0 + per_unit);
+                const uint8_t out_kind = n_units > 1 ? kJobPart : kJobRow;
+                const uint32_t out_dst = n_units > 1 ? unit_base + u : 0u;
+                const uint32_t G = (u1 - u0 + F - 1) / F;
+                if (G == 1) {  // one fan-in group: packed with other small rows
+                    uint64_t dep = 0;
+                    for (uint32_t q = u0; q < u1; q++) dep = std::max(dep, pieces[first_piece + q].dep);
+                    packs.push_back(Pack{first_piece + u0, u1 - u0, dep, out_kind, out_dst, i});
+                    continue;
+                }
+                std::vector<Group> groups(G);
+                for (uint32_t g = 0; g < G; g++) {
+                    const uint32_t q0 = u0 + g * F, q1 = std::min(u1, q0 + F);
+                    uint64_t dep = 0;
+                    for (uint32_t q = q0; q < q1; q++) dep = std::max(dep, pieces[first_piece + q].dep);
+                    groups[g] = Group{first_piece + q0, q1 - q0, dep};
+                }
+                // the finisher keeps the groups that depend on the most recently written rows (they wait longest)
+                std::vector<uint32_t> order(G);
+                for (uint32_t g = 0; g < G; g++) order[g] = g;
+                std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return groups[x].dep < groups[y].dep; });
+                const uint32_t n_own = std::min(G, std::max(1u, c->wide_finish));
+                std::vector<uint32_t> own(order.end() - n_own, order.end());   // oldest dependency first, the latest last
+                std::vector<uint32_t> rest(order.begin(), order.end() - n_own);
+                std::sort(rest.begin(), rest.end());
+                const uint32_t l0_base = slots;
+                if (!rest.empty()) slots += G;
+                // helpers: `wide_span` groups each, group sums written through to HBM
+                for (size_t h0 = 0; h0 < rest.size(); h0 += std::max(1u, c->wide_span)) {
+                    Prog g;
+                    std::vector<Piece> ph;
+                    std::vector<WJob> js;
+                    for (size_t h = h0; h < std::min(rest.size(), h0 + std::max(1u, c->wide_span)); h++) {
+                        const Group &gr = groups[rest[h]];
+                        if (ph.size() + gr.n > pslots) { close_phase(g, ph, lo); add_pass(g, js); }
+                        js.push_back(WJob{(uint16_t)ph.size(), (uint16_t)gr.n, kJobPart, (uint8_t)g.phases, 0, 0, l0_base + rest[h], i});
+                        for (uint32_t q = 0; q < gr.n; q++) ph.push_back(slotted(pieces[gr.first + q], ph.size()));
+                    }
+                    close_phase(g, ph, lo);
+                    add_pass(g, js);
+                    helpers.push_back(std::move(g));
+                }
+                // finisher: its own groups (sums -> LDS), the helpers' sums imported before its last phase, then the unit's sum
+                {
+                    Prog g;
+                    std::vector<Piece> ph;
+                    std::vector<WJob> js, imports;
+                    for (uint32_t r : rest) imports.push_back(WJob{0, 0, kJobImport, 0, 0, 0, pslots + r, l0_base + r});
+                    // phases of the own groups, in `own` order; the last phase starts with the last group that does not fit the one before
+                    std::vector<std::vector<uint32_t>> phases(1);
+                    {
+                        uint32_t used = 0;
+                        for (uint32_t g2 : own) {
+                            if (used + groups[g2].n > pslots) { phases.emplace_back(); used = 0; }
+                            phases.back().push_back(g2);
+                            used += groups[g2].n;
+                        }
+                    }
+                    for (size_t f = 0; f < phases.size(); f++) {
+                        if (f + 1 == phases.size() && !imports.empty()) {  // imports run before the last phase's rounds
+                            for (WJob &w : imports) w.phase = f == 0 ? kJobBefore : (uint8_t)(f - 1);
+                            add_pass(g, imports);
+                        }
+                        for (uint32_t g2 : phases[f]) {
+                            const Group &gr = groups[g2];
+                            js.push_back(WJob{(uint16_t)ph.size(), (uint16_t)gr.n, kJobLds, (uint8_t)f, 0, 0, pslots + g2, i});
+                            for (uint32_t q = 0; q < gr.n; q++) ph.push_back(slotted(pieces[gr.first + q], ph.size()));
+                        }
+                        close_phase(g, ph, lo);
+                        add_pass(g, js);
+                    }
+                    std::vector<WJob> fin{WJob{(uint16_t)pslots, (uint16_t)G, out_kind, (uint8_t)(phases.size() - 1), 0, 0, out_dst, i}};
+                    add_pass(g, fin);
+                    finishers.push_back(std::move(g));
+                }
+            }
+        }
+        // whole rows and one-group units, packed: independent ones first (longest first), then by the age of what they wait for
+        {
+            std::vector<uint32_t> order(packs.size());
+            for (uint32_t x = 0; x < order.size(); x++) order[x] = x;
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+                const Pack &a = packs[x], &b = packs[y];
+                if ((a.dep != 0) != (b.dep != 0)) return a.dep == 0;
+                if (a.dep != b.dep) return a.dep < b.dep;
+                return a.n > b.n;
+            });
+            std::vector<char> taken(packs.size(), 0);
+            size_t head = 0;
+            while (head < order.size()) {
+                Prog g;
+                std::vector<Piece> ph;
+                std::vector<WJob> js;
+                for (uint32_t f = 0; f < std::max(1u, c->wide_phases); f++) {
+                    size_t scanned = 0;
+                    for (size_t x = head; x < order.size() && ph.size() < pslots && scanned < 64; x++) {
+                        if (taken[order[x]]) continue;
+                        scanned++;
+                        const Pack &pk = packs[order[x]];
+                        if (ph.size() + pk.n > pslots) continue;
+                        taken[order[x]] = 1;
+                        if (!(pieces[pk.first].it.flags & kItemDirect))
+                            js.push_back(WJob{(uint16_t)ph.size(), (uint16_t)pk.n, pk.kind, (uint8_t)f, 0, 0, pk.dst, pk.row});
+                        for (uint32_t q = 0; q < pk.n; q++) ph.push_back(slotted(pieces[pk.first + q], ph.size()));
+                    }
+                    while (head < order.size() && taken[order[head]]) head++;
+                    if (ph.empty()) break;
+                    close_phase(g, ph, lo);
+                    add_pass(g, js);
+                }
+                if (!g.items.empty()) packed.push_back(std::move(g));
+            }
+        }
+        // descriptors: helpers, finishers, packed
+        auto emit = [&](std::vector<Prog> &v) {
+            for (Prog &g : v) {
+                WideDesc d{};
+                d.lo = lo;
+                d.index = b0 + k;
+                d.kind = 0;
+                d.a = (uint32_t)(c->h_items.size() - p.item_off);
+                d.b = (uint32_t)(g.items.size() / ipb);
+                d.c = (uint32_t)(c->h_jobs.size() - p.job_off);
+                d.d = (uint32_t)g.jobs.size();
+                c->h_items.insert(c->h_items.end(), g.items.begin(), g.items.end());
+                c->h_jobs.insert(c->h_jobs.end(), g.jobs.begin(), g.jobs.end());
+                c->h_wide.push_back(d);
+                mb_items += (uint32_t)g.items.size();
+                p.n_wgs++;
+            }
+        };
+        p.n_helpers += (uint32_t)helpers.size();
+        p.n_finishers += (uint32_t)finishers.size();
+        p.n_packed += (uint32_t)packed.size();
+        emit(helpers);
+        emit(finishers);
+        emit(packed);
+        // the combine trees above the units of rows with more than F*F pieces, level by level
+        const uint32_t fin_first = (uint32_t)(c->h_hubs.size() - p.fin_off);
+        uint32_t fin_n = 0;
+        for (int level = 0; !cur.empty(); level++) {
+            nxt.clear();
+            for (const Node &nd : cur) {
+                const uint32_t G = (level == kMaxFinLevels - 1) ? nd.n : F;
+                const uint32_t nout = (nd.n + G - 1) / G;
+                if (nout == 1) {
+                    c->h_hubs.push_back(FinItem{nd.in_slot, nd.n, kFinToStage, nd.row});
+                    fin_n++;
+                } else {
+                    for (uint32_t o = 0; o < nout; o++) {
+                        c->h_hubs.push_back(FinItem{nd.in_slot + o * G, std::min(G, nd.n - o * G), slots + o, nd.row});
+                        fin_n++;
+                    }
+                    nxt.push_back(Node{nd.row, slots, nout});
+                    slots += nout;
+                }
+            }
+            cur.swap(nxt);
+        }
+        while (fin_n % 4u != 0) { c->h_hubs.push_back(FinItem{0, 0, kFinToStage, 0}); fin_n++; }
+        for (uint32_t wn = 0; wn < fin_n / 4u; wn++) {
+            WideDesc d{};
+            d.lo = lo;
+            d.index = b0 + k;
+            d.kind = 1;
+            d.a = fin_first;
+            d.b = fin_n;
+            d.c = wn;
+            c->h_wide.push_back(d);
+            p.n_wgs++;
+            p.n_node_wgs++;
+        }
+        p.nnz += nnz;
+        if (c->count_compulsory) p.compulsory += compulsory_bytes(c, lo, hi, walk, nnz, mb_items);
+    }
+    p.n_slots = slots;
+    if (slots > kItemSlotMask) c->plan_overflow = true;
+    c->max_slots = std::max<size_t>(c->max_slots, slots);
+    return c->wides.emplace(key, p).first->second;
+}
+
 // Make every plan built so far resident in HBM (and the partial-sum buffer large enough).
 int upload_plans(f2v_ctx *c) {
     if (c->plan_overflow) {
@@ -602,9 +925,30 @@ int upload_plans(f2v_ctx *c) {
     const size_t need_slots = c->max_slots;
     const bool grow_items = c->h_items.size() > c->d_items_cap, grow_hubs = c->h_hubs.size() > c->d_hubs_cap;
     const bool grow_slots = need_slots > c->partial_slots;
-    if (c->h_items.size() == c->d_items_valid && c->h_hubs.size() == c->d_hubs_valid && c->h_wg.size() == c->d_wg_valid && !grow_slots)
+    if (c->h_items.size() == c->d_items_valid && c->h_hubs.size() == c->d_hubs_valid && c->h_wg.size() == c->d_wg_valid &&
+        c->h_wide.size() == c->d_wide_valid && c->h_jobs.size() == c->d_jobs_valid && !grow_slots)
         return F2V_OK;  // O(1) steady state
     HIPC(hipStreamSynchronize(c->stream));  // launches in flight read these buffers
+    if (c->h_wide.size() > c->d_wide_cap) {
+        if (c->d_wide) (void)hipFree(c->d_wide);
+        c->d_wide = nullptr;
+        c->d_wide_cap = std::max<size_t>(c->h_wide.size() * 3 / 2, 1024);
+        HIPC(hipMalloc((void **)&c->d_wide, c->d_wide_cap * sizeof(WideDesc)));
+        c->d_wide_valid = 0;
+    }
+    if (c->h_wide.size() > c->d_wide_valid)
+        HIPC(hipMemcpy(c->d_wide + c->d_wide_valid, c->h_wide.data() + c->d_wide_valid, (c->h_wide.size() - c->d_wide_valid) * sizeof(WideDesc), hipMemcpyHostToDevice));
+    c->d_wide_valid = c->h_wide.size();
+    if (c->h_jobs.size() > c->d_jobs_cap) {
+        if (c->d_jobs) (void)hipFree(c->d_jobs);
+        c->d_jobs = nullptr;
+        c->d_jobs_cap = std::max<size_t>(c->h_jobs.size() * 3 / 2, 1024);
+        HIPC(hipMalloc((void **)&c->d_jobs, c->d_jobs_cap * sizeof(WJob)));
+        c->d_jobs_valid = 0;
+    }
+    if (c->h_jobs.size() > c->d_jobs_valid)
+        HIPC(hipMemcpy(c->d_jobs + c->d_jobs_valid, c->h_jobs.data() + c->d_jobs_valid, (c->h_jobs.size() - c->d_jobs_valid) * sizeof(WJob), hipMemcpyHostToDevice));
+    c->d_jobs_valid = c->h_jobs.size();
     if (c->h_wg.size() > c->d_wg_cap) {
         if (c->d_wg) (void)hipFree(c->d_wg);
         c->d_wg = nullptr;
@@ -720,6 +1064,11 @@ int kernel_gave_up(f2v_ctx *c, const char *where, const uint32_t *e) {
     c->upd_lo = c->upd_hi = 0;
     c->have_x = false;
     c->x_invalid = true;
+    if (e[0] == 4u)  // a finisher's import: err[2] waiting workgroup, [3] partial-sum slot, [4] flag seen, [5] launch, [6] grid, [7] the minibatch's first row
+        return fail(F2V_ESTATE, "%s: a chained launch was lost: %u waits for a helper's group sum gave up (first: workgroup %u of %u, minibatch starting at row %u, "
+                    "partial-sum slot %u: flag %u, launch %u); the embeddings are invalid from that launch on (set or initialise them again); this handle now runs one "
+                    "launch per minibatch and per combine-tree level (\"merge_finalize\" = 0)",
+                    where, e[1], e[2], e[6], e[7], e[3], e[4], e[5]);
     if (e[0] == 3u)  // wait_row_slow: err[2] waiting workgroup, [3] row, [4] flag seen, [5] launch, [6] grid, [7] the minibatch's first row
         return fail(F2V_ESTATE, "%s: a chained launch was lost: %u row waits gave up (first: workgroup %u of %u, minibatch starting at row %u, waiting for row %u: "
                     "flag %u, launch %u); the embeddings are invalid from that launch on (set or initialise them again); this handle now runs one launch "
@@ -807,6 +1156,7 @@ int launch_step(f2v_ctx *c, int math, uint32_t batch_lo, uint32_t batch_hi, uint
         if (a.seq == 0) a.seq = ++c->launch_seq;  // 0 is what fresh flags hold
 #ifdef F2V_TEST_HOOKS
         a.test_withhold_slot = c->test_withhold_slot;
+        a.test_withhold_row = kNoSlot;  // (chained launches only)
 #endif
         blocks += (a.fin_n + wpb - 1) / wpb;
     }
@@ -944,6 +1294,7 @@ int launch_chain(f2v_ctx *c, int math, const ChainPlan &plan, const uint32_t *d_
     if (a.seq == 0) a.seq = ++c->launch_seq;
 #ifdef F2V_TEST_HOOKS
     a.test_withhold_slot = c->test_withhold_slot;
+    a.test_withhold_row = c->test_withhold_row;
 #endif
     a.rowflag = c->d_rowflag;
     a.chain_lo = plan.lo;
@@ -970,6 +1321,76 @@ int launch_chain(f2v_ctx *c, int math, const ChainPlan &plan, const uint32_t *d_
     }
 #undef F2V_C
 #undef F2V_C2
+    HIPC(hipGetLastError());
+    if (c->upd_hi == c->upd_lo) c->upd_lo = plan.lo;
+    c->upd_hi = plan.hi;
+    c->pending = true;
+    c->p_lo = plan.last_lo;
+    c->p_hi = plan.hi;
+    c->stats.hub_rows += plan.n_hubs;
+    c->stats.hub_chunks += plan.n_chunks;
+    c->stats.step_launches += 1;
+    c->stats.rows += plan.hi - plan.lo;
+    c->stats.nnz += plan.nnz;
+    c->stats.algorithmic_bytes += plan.nnz * (4ull * c->D + 4) + (uint64_t)(plan.hi - plan.lo) * (8ull * c->D + 4) + (uint64_t)plan.n_batches * ns * (4ull * c->D + 4);
+    c->stats.compulsory_bytes += plan.compulsory;
+    return F2V_OK;
+}
+
+
+// One launch of the wide form (qwide_chain_kernel): minibatches [plan.first_batch, +plan.n_batches)
+int launch_wide(f2v_ctx *c, int math, const WidePlan &plan, const uint32_t *d_ids_epoch, uint32_t ids_stride, uint32_t ns, float lr, int bs_mode) {
+    int rc;
+    if (c->upd_hi != c->upd_lo && plan.lo != c->upd_hi) {
+        if ((rc = flush_pending(c)) != F2V_OK) return rc;
+    }
+    WideArgs wa{};
+    StepArgs &a = wa.base;
+    a.X = c->d_X[c->cur];
+    a.Xn = c->d_X[c->cur ^ 1];
+    a.rowptr = c->d_rowptr;
+    a.nbr_ids = math == 7 ? c->d_walks : c->d_colids;
+    a.partials = c->d_partials;
+    a.items = c->d_items + plan.item_off;
+    a.sm_table = c->d_table;
+    a.D = c->D;
+    a.upd_lo = (c->upd_hi == c->upd_lo) ? plan.lo : c->upd_lo;
+    a.ns = ns;
+    a.bs_mode = bs_mode ? 1u : 0u;
+    a.lr = lr;
+    a.fin_items = c->d_hubs + plan.fin_off;
+    a.ready = c->d_ready;
+    a.err = c->d_kerr;
+    a.timeout_ticks = (unsigned long long)std::min(c->tree_timeout_ms, c->chain_timeout_ms) * 100000ull;
+    a.seq = ++c->launch_seq;
+    if (a.seq == 0) a.seq = ++c->launch_seq;
+#ifdef F2V_TEST_HOOKS
+    a.test_withhold_slot = c->test_withhold_slot;
+    a.test_withhold_row = c->test_withhold_row;
+#endif
+    a.rowflag = c->d_rowflag;
+    a.chain_lo = plan.lo;
+#ifdef F2V_TEST_HOOKS
+    if (c->test_chain_nowait) a.chain_lo = 0xFFFFFFFFu;
+    a.stamps = c->d_stamps;
+#endif
+    wa.wg = c->d_wide + plan.wg_off;
+    wa.jobs = c->d_jobs + plan.job_off;
+    wa.ids = d_ids_epoch;
+    wa.ids_stride = ids_stride;
+    const uint32_t width = subwave_width(c);
+    const bool full = width == c->D;
+    const int o = (math == 5) ? 5 : 6;
+#define F2V_W2(OPT, LPI, NB, U, FULL) hipLaunchKernelGGL((qwide_chain_kernel<OPT, LPI, NB, U, FULL>), dim3(plan.n_wgs), dim3(256), 0, c->stream, wa)
+#define F2V_W(OPT, LPI, NB, U) do { if (full) F2V_W2(OPT, LPI, NB, U, true); else F2V_W2(OPT, LPI, NB, U, false); } while (0)
+    switch (width) {
+        case 32: if (o == 5) F2V_W(5, 8, 1, 8); else F2V_W(6, 8, 1, 8); break;
+        case 64: if (o == 5) F2V_W(5, 16, 1, 8); else F2V_W(6, 16, 1, 8); break;
+        case 128: if (o == 5) F2V_W(5, 16, 2, 4); else F2V_W(6, 16, 2, 4); break;
+        default: if (o == 5) F2V_W(5, 16, 4, 4); else F2V_W(6, 16, 4, 4); break;
+    }
+#undef F2V_W
+#undef F2V_W2
     HIPC(hipGetLastError());
     if (c->upd_hi == c->upd_lo) c->upd_lo = plan.lo;
     c->upd_hi = plan.hi;
@@ -1237,6 +1658,7 @@ int f2v_create(const uint32_t *rowptr, const uint32_t *colids, uint32_t n, uint6
     if (const char *e = getenv("F2V_RECOVER")) c->recover = atoi(e) != 0;  // default of "recover" for new handles
 #ifdef F2V_TEST_HOOKS
     if (const char *e = getenv("F2V_TEST_WITHHOLD_SLOT")) c->test_withhold_slot = (uint32_t)strtoul(e, nullptr, 0);  // f2v_test_withhold_flag from outside
+    if (const char *e = getenv("F2V_TEST_WITHHOLD_ROW")) c->test_withhold_row = (uint32_t)strtoul(e, nullptr, 0);
 #endif
     {
         // Dispatch probe: the one-launch minibatch (combine-tree nodes waiting inside the step kernel's grid) counts on
@@ -1273,7 +1695,7 @@ int f2v_destroy(f2v_handle c) {
     (void)hipSetDevice(c->device);
     (void)push_detach(c);
     void *ptrs[] = {c->d_rowptr, c->d_colids, c->d_walks, c->d_walks_alt, c->d_ids, c->d_X[0], c->d_X[1],
-                    c->d_partials, c->d_table, c->d_items, c->d_hubs, c->d_ready, c->d_kerr, c->d_wg, c->d_rowflag, c->d_snap, c->push.flags, c->push.d_err, c->push.d_masks, c->push.d_patch, c->push.landing_buf};
+                    c->d_partials, c->d_table, c->d_items, c->d_hubs, c->d_ready, c->d_kerr, c->d_wg, c->d_rowflag, c->d_snap, c->d_wide, c->d_jobs, c->push.flags, c->push.d_err, c->push.d_masks, c->push.d_patch, c->push.landing_buf};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 #ifdef F2V_TEST_HOOKS
@@ -1495,6 +1917,11 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
         c->chain_max_batch = (uint32_t)value;
         return F2V_OK;
     }
+    if (!strcmp(name, "wide_max_batch")) {
+        if (value < 0 || value > 0xFFFFFFFFll) return fail(F2V_EINVAL, "wide_max_batch out of range");
+        c->wide_max_batch = (uint32_t)value;
+        return F2V_OK;
+    }
     if (!strcmp(name, "chain_rows")) {  // rows one chained launch covers
         if (value < 2 || value > 0x7FFFFFFFll) return fail(F2V_EINVAL, "chain_rows out of range");
         HIPC(hipSetDevice(c->device));
@@ -1508,6 +1935,19 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
     if (!strcmp(name, "tree_timeout_ms")) {
         if (value < 1 || value > 600000) return fail(F2V_EINVAL, "tree_timeout_ms must be 1..600000");
         c->tree_timeout_ms = value;
+        return F2V_OK;
+    }
+    if (!strcmp(name, "chain_wide") || !strcmp(name, "wide_phases") || !strcmp(name, "wide_span") || !strcmp(name, "wide_finish")) {
+        if (name[0] == 'w' && (value < 1 || value > 64)) return fail(F2V_EINVAL, "%s must be 1..64", name);
+        HIPC(hipSetDevice(c->device));
+        int rc = flush_pending(c);
+        if (rc != F2V_OK) return rc;
+        HIPC(hipStreamSynchronize(c->stream));
+        if (!strcmp(name, "chain_wide")) c->wide = value != 0;
+        else if (!strcmp(name, "wide_phases")) c->wide_phases = (uint32_t)value;
+        else if (!strcmp(name, "wide_span")) c->wide_span = (uint32_t)value;
+        else c->wide_finish = (uint32_t)value;
+        drop_plans(c);
         return F2V_OK;
     }
     if (!strcmp(name, "chain_timeout_ms")) {
@@ -1562,6 +2002,12 @@ int f2v_get_param(f2v_handle c, const char *name, int64_t *out) {
     if (!strcmp(name, "tree_timeout_ms")) { *out = c->tree_timeout_ms; return F2V_OK; }
     if (!strcmp(name, "chain_batches")) { *out = c->chain ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "chain_timeout_ms")) { *out = c->chain_timeout_ms; return F2V_OK; }
+    if (!strcmp(name, "chain_wide")) { *out = c->wide ? 1 : 0; return F2V_OK; }
+    if (!strcmp(name, "wide_phases")) { *out = c->wide_phases; return F2V_OK; }
+    if (!strcmp(name, "wide_max_batch")) { *out = c->wide_max_batch; return F2V_OK; }
+    if (!strcmp(name, "wide_span")) { *out = c->wide_span; return F2V_OK; }
+    if (!strcmp(name, "wide_finish")) { *out = c->wide_finish; return F2V_OK; }
+    if (!strcmp(name, "last_train_form")) { *out = c->last_train_form; return F2V_OK; }
     if (!strcmp(name, "recover")) { *out = c->recover ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "recoveries")) { *out = c->recoveries; return F2V_OK; }
     if (!strcmp(name, "chain_max_batch")) { *out = c->chain_max_batch; return F2V_OK; }
@@ -1854,8 +2300,12 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
     const bool all_upfront = (math != 7 || c->fast_rng) && (per_epoch * iters * 4ull <= (1ull << 30));
     // small minibatches: groups of them in one launch (chain_plan_for), ordered by data dependencies instead of launch boundaries
     const bool chained = iters > 0 && chain_usable(c, math, batch, bs_mode, sharded);
+    const bool wide = chained && wide_usable(c) && batch <= c->wide_max_batch;
     const uint32_t K = chained ? chain_len(c, batch) : 1;
-    if (chained) {
+    c->last_train_form = wide ? 2 : chained ? 1 : 0;
+    if (wide) {
+        for (uint32_t b0 = 0; b0 < nb; b0 += K) (void)wide_plan_for(c, b0, std::min(K, nb - b0), batch, math == 7);
+    } else if (chained) {
         for (uint32_t b0 = 0; b0 < nb; b0 += K) (void)chain_plan_for(c, b0, std::min(K, nb - b0), batch, math == 7);
     } else {
         for (uint32_t b = 0; b < nb; b++) {  // all launch plans up-front: one upload, no syncs inside the timed loop
@@ -2085,7 +2535,13 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
             cv.notify_all();
             HIPC(he);
         }
-        if (chained) {
+        if (wide) {
+            for (uint32_t b0 = 0; b0 < nb; b0 += K) {
+                const WidePlan plan = wide_plan_for(c, b0, std::min(K, nb - b0), batch, math == 7);
+                if ((rc = upload_plans(c)) != F2V_OK) return rc;
+                if ((rc = launch_wide(c, math, plan, d_epoch_ids, (uint32_t)stride, ns, lr, bs_mode)) != F2V_OK) return rc;
+            }
+        } else if (chained) {
             for (uint32_t b0 = 0; b0 < nb; b0 += K) {
                 const ChainPlan plan = chain_plan_for(c, b0, std::min(K, nb - b0), batch, math == 7);
                 if ((rc = upload_plans(c)) != F2V_OK) return rc;  // O(1) unless the plan cache was dropped meanwhile
@@ -2289,6 +2745,12 @@ int f2v_push_attach(f2v_handle c, uint32_t rank, uint32_t world, const void *all
 int f2v_test_withhold_flag(f2v_handle c, uint32_t slot) {
     if (!c) return fail(F2V_EINVAL, "null handle");
     c->test_withhold_slot = slot;
+    return F2V_OK;
+}
+
+int f2v_test_withhold_row(f2v_handle c, uint32_t row) {
+    if (!c) return fail(F2V_EINVAL, "null handle");
+    c->test_withhold_row = row;
     return F2V_OK;
 }
 

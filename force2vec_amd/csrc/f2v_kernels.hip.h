@@ -113,6 +113,7 @@ struct StepArgs {
     // f2v_test_stamps: per row four 100-MHz wall-clock words -- [0] its last hub piece announced, [1] its last inner tree node
     // announced, [2] its row flag stored, [3] ~(first time a waiter that had to wait saw that flag); nullptr: off
     unsigned long long *stamps;
+    uint32_t test_withhold_row;       // f2v_test_withhold_row: chained launches never store this row's flag (kNoSlot: none)
 #endif
 };
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
@@ -476,6 +477,7 @@ struct FinalizeTreeArgs {
     uint32_t first_dep;       // items from this index on add sums produced INSIDE this launch
 #ifdef F2V_TEST_HOOKS
     unsigned long long *stamps;
+    uint32_t test_withhold_row;
 #endif
 };
 
@@ -605,6 +607,9 @@ __device__ __forceinline__ void finalize_tree_node(const FinalizeTreeArgs &a, ui
         if constexpr (ROW_THROUGH) {
             store_row_agent<VEC, EXACT>(f.Xn + (size_t)h.row * D, lane, D, Y);
             __builtin_amdgcn_s_waitcnt(0);  // the row is in memory before it is announced
+#ifdef F2V_TEST_HOOKS
+            if (h.row == a.test_withhold_row) return;  // fault injection: this row is never announced
+#endif
             if (lane == 0) __hip_atomic_store(a.rowflag + h.row, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef F2V_TEST_HOOKS
             if (a.stamps && lane == 0) a.stamps[4 * (size_t)h.row + 2] = wall_clock64();
@@ -761,6 +766,18 @@ __device__ __forceinline__ const float *row_src(const StepArgs &a, uint32_t j, u
     return ((j - a.upd_lo) < a.upd_rows ? a.Xn : a.X) + (size_t)j * D;
 }
 
+// 16 bytes of a row that another workgroup of THIS launch has written (written through, sc1) and announced: loaded at agent
+// scope (global_load_dwordx2 sc1 twice: past the L1, which no store of another CU ever refreshes) -- the measured hand-off
+// recipe of MI355X_MICROARCH.md: sc1 stores, the storing wave's vmcnt(0), sc1 flag store, sc1 poll, and EVERY load of the
+// handed-off bytes an sc1 load.  Only rows of the launch's own earlier minibatches (~2 % of the gathers) are read this way.
+__device__ __forceinline__ float4 load16_agent(const float *p) {
+    const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p);
+    const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float4(__builtin_bit_cast(float, (uint32_t)lo), __builtin_bit_cast(float, (uint32_t)(lo >> 32)),
+                       __builtin_bit_cast(float, (uint32_t)hi), __builtin_bit_cast(float, (uint32_t)(hi >> 32)));
+}
+
 // One item's list of row ids; `cnt` is this item's length, `maxcnt` the wave's (uniform).
 // U rows per item are in flight before the first interaction is evaluated; the ids of the next group are
 // fetched one group ahead.
@@ -777,14 +794,17 @@ __device__ __forceinline__ void qprocess(const StepArgs &a, const uint32_t *ids,
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (g + u < cnt) {
+                bool handed = false;  // the row was written inside this launch: wait for its flag, then agent-scope loads
                 if constexpr (CHAIN) {
-                    if ((j[u] - a.chain_lo) < a.chain_rows) bad = wait_row(a, j[u]) || bad;
+                    handed = (j[u] - a.chain_lo) < a.chain_rows;
+                    if (handed) bad = wait_row(a, j[u]) || bad;
                 }
                 const float *src = row_src(a, j[u], D) + t * 4;
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
-                    if (FULL || 4u * LPI * b + 4u * t < D) xj[u][b] = *reinterpret_cast<const float4 *>(src + 4 * LPI * b);
-                    else xj[u][b] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (!(FULL || 4u * LPI * b + 4u * t < D)) xj[u][b] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    else if (CHAIN && handed) xj[u][b] = load16_agent(src + 4 * LPI * b);
+                    else xj[u][b] = *reinterpret_cast<const float4 *>(src + 4 * LPI * b);
                 }
             }
         }
@@ -795,6 +815,45 @@ __device__ __forceinline__ void qprocess(const StepArgs &a, const uint32_t *ids,
             if (g + u < cnt) pair_update_q<OPT, LPI, NB, NEG>(xi, xj[u], Y, a.lr, c0, table);
         }
     }
+}
+
+// The same walk for the rounds of a wide program (always a chained launch, always attracting neighbours): the first U ids of
+// the list arrive in `j` (loaded a round ago), and once the list's last gathers have been issued the first U ids of the NEXT
+// round's list are requested into `j` -- behind the gathers, so that waiting for the rows does not wait for them.  A round
+// then costs one memory latency (the rows) instead of three dependent ones (item, ids, rows).
+template <int OPT, int LPI, int NB, int U, bool FULL>
+__device__ __forceinline__ void qprocess_pre(const StepArgs &a, const uint32_t *ids, uint32_t cnt, uint32_t maxcnt, uint32_t t, uint32_t D,
+                                             const float (&xi)[NB][4], float (&Y)[NB][4], double c0, const float *table, bool &bad,
+                                             uint32_t (&j)[U], const uint32_t *next_ids, uint32_t next_cnt) {
+    uint32_t g = 0;
+    do {
+        float4 xj[U][NB];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (g + u < cnt) {
+                const bool handed = (j[u] - a.chain_lo) < a.chain_rows;
+                if (handed) bad = wait_row(a, j[u]) || bad;
+                const float *src = row_src(a, j[u], D) + t * 4;
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    if (!(FULL || 4u * LPI * b + 4u * t < D)) xj[u][b] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    else if (handed) xj[u][b] = load16_agent(src + 4 * LPI * b);
+                    else xj[u][b] = *reinterpret_cast<const float4 *>(src + 4 * LPI * b);
+                }
+            }
+        }
+        const bool last = g + U >= maxcnt;  // (uniform)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (last) j[u] = ((uint32_t)u < next_cnt) ? next_ids[u] : 0u;
+            else j[u] = (g + U + u < cnt) ? ids[g + U + u] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (g + u < cnt) pair_update_q<OPT, LPI, NB, false>(xi, xj[u], Y, a.lr, c0, table);
+        }
+        g += U;
+    } while (g < maxcnt);
 }
 
 // the largest value any item of the wave holds (the value is uniform inside an item): a scalar
@@ -829,6 +888,7 @@ __device__ __forceinline__ void qstep_body(const StepArgs &a, const uint32_t blk
         ft.ready = a.ready; ft.err = a.err; ft.timeout_ticks = a.timeout_ticks; ft.seq = a.seq; ft.first_dep = 0u; ft.rowflag = a.rowflag;
 #ifdef F2V_TEST_HOOKS
         ft.stamps = a.stamps;
+        ft.test_withhold_row = a.test_withhold_row;
 #endif
         const uint32_t node = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blk - a.step_blocks) * wpb + (threadIdx.x >> 6)));
         finalize_tree_node<OPT, FVEC, (FULL && DP % 64u == 0u), CHAIN>(ft, node, lane);
@@ -853,12 +913,16 @@ __device__ __forceinline__ void qstep_body(const StepArgs &a, const uint32_t blk
     if (lds_samples) {
         for (uint32_t k = threadIdx.x; k < a.ns * (DP / 4); k += blockDim.x) {
             const uint32_t sidx = k / (DP / 4), c4 = k % (DP / 4);
+            bool handed = false;
             if constexpr (CHAIN) {
                 const uint32_t sj = a.sample_ids[sidx];
-                if ((sj - a.chain_lo) < a.chain_rows) smp_bad = wait_row(a, sj) || smp_bad;
+                handed = (sj - a.chain_lo) < a.chain_rows;
+                if (handed) smp_bad = wait_row(a, sj) || smp_bad;
             }
-            smp[sidx][c4] = (FULL || 4u * c4 < D) ? reinterpret_cast<const float4 *>(row_src(a, a.sample_ids[sidx], D))[c4]
-                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float *srow = row_src(a, a.sample_ids[sidx], D);
+            smp[sidx][c4] = !(FULL || 4u * c4 < D) ? make_float4(0.f, 0.f, 0.f, 0.f)
+                            : (CHAIN && handed)    ? load16_agent(srow + 4 * c4)
+                                                   : reinterpret_cast<const float4 *>(srow)[c4];
         }
     }
     if constexpr (CHAIN) {
@@ -961,7 +1025,12 @@ __device__ __forceinline__ void qstep_body(const StepArgs &a, const uint32_t blk
     if constexpr (PUSH) __builtin_amdgcn_s_waitcnt(0);  // the peers' memory has acknowledged this wave's rows
     if constexpr (CHAIN) {
         __builtin_amdgcn_s_waitcnt(0);  // new rows are in memory before they are announced to the later minibatches of the launch
-        if (active && !partial && t == 0u) __hip_atomic_store(a.rowflag + row, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef F2V_TEST_HOOKS
+        if (active && !partial && t == 0u && row != a.test_withhold_row)
+#else
+        if (active && !partial && t == 0u)
+#endif
+            __hip_atomic_store(a.rowflag + row, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef F2V_TEST_HOOKS
         if (a.stamps && active && !partial && t == 0u) a.stamps[4 * (size_t)row + 2] = wall_clock64();
 #endif
@@ -1037,6 +1106,313 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? 5 : 1) void qstep_chain_
     a.fin_items = bd.fin_n ? c.base.fin_items + bd.fin_off : nullptr;
     a.fin_n = bd.fin_n;
     qstep_body<OPT, LPI, NB, U, false, FULL, true>(a, bd.blk);
+}
+
+// ---- chained minibatches, wide form: a split row's pieces meet in LDS ------------------------------------------------
+// qstep_chain_kernel above hands a split row's partial sums from workgroup to workgroup through HBM: piece -> ready flag ->
+// tree node -> ready flag -> (tree node ->) row flag -- three or four global hand-offs (written-through store, its
+// acknowledgement, a flag store, an L2-missing poll, agent-scope loads) on every hop of the row-to-row dependency chain that
+// bounds small minibatches (profiles/r03_chain_hops_baseline.txt).  Here the pieces of a row meet INSIDE one workgroup:
+//   * a workgroup runs a PROGRAM of rounds (one piece, or one whole low-degree row, per lane group and round); a piece's
+//     force sum goes to an LDS slot instead of HBM; inside a phase the pieces run in the order of what they wait for (the
+//     ones that read the most recently written rows in the last round), whatever their slots;
+//   * when a PHASE of rounds ends, JOBS add slots in order, 32 lanes per job, 8 jobs side by side: the same chunk order and
+//     the same fan-in groups as the combine tree (piece sums of one fan-in group are added first to last, then the groups'
+//     sums first to last), so every bit is the one the tree -- and the oracle's restatement of it -- produces;
+//   * a row of up to `fanin` pieces is finished by one job (x_i added, ONE written-through row, ONE row flag); several such
+//     rows share a workgroup;
+//   * a row (or, beyond fanin^2 pieces, each fanin^2-piece unit of it) of several fan-in groups has a FINISHER workgroup that
+//     owns the groups whose neighbours were updated most recently -- the ones that will wait longest -- runs them last, and
+//     adds all groups' sums itself; the other groups are computed ahead of time by HELPER workgroups (smaller index) whose
+//     group sums travel through HBM (written through + ready flag) and are imported into the finisher's LDS before its last
+//     phase.  After the last awaited neighbour row has arrived, what is left is one gather, one in-LDS group sum, one in-LDS
+//     sum of the groups' sums and the row store: one global hand-off per hop instead of three or four;
+//   * rows of more than fanin^2 pieces keep combine-tree nodes for the levels above their units' sums (finalize_tree_node).
+// Waits only ever point at smaller workgroup indices (rows of earlier minibatches; a unit's helpers), as before.
+struct WJob {            // 16 bytes
+    uint16_t src, n;     // LDS slots [src, src + n) are added in order (kJobImport: unused)
+    uint8_t kind;        // kJob*
+    uint8_t phase;       // the job runs when this phase of the workgroup's program has ended (kJobBefore: before the first round)
+    uint8_t pass_len;    // jobs [this, this + pass_len) run side by side (<= 8): set on every job of the pass
+    uint8_t pad;
+    uint32_t dst;        // kJobLds, kJobImport: LDS slot; kJobPart: partial-sum slot in HBM
+    uint32_t row;        // kJobRow / kJobPart: the row; kJobImport: the partial-sum slot in HBM that is fetched
+};
+constexpr uint8_t kJobLds = 0, kJobPart = 1, kJobRow = 2, kJobImport = 3;
+constexpr uint8_t kJobBefore = 255;
+constexpr uint32_t kItemDirect = 1u << 28;    // wide programs: a whole row -- its new embedding is stored by the item itself
+constexpr uint32_t kItemPhaseEnd = 1u << 27;  // ... the round this item belongs to is the last of its phase (on every item of the round)
+constexpr uint32_t kItemIdle = 1u << 26;      // ... filler: nothing to compute, nothing to store
+constexpr uint32_t kItemPieceSlot = 0xFFu;    // ... a piece's LDS slot (the order in which a job adds): pieces are RUN in the order of what they wait for
+constexpr uint32_t kWideSumSlots = 32;        // LDS slots for fan-in group sums, behind the piece slots
+
+struct WideDesc {        // one per workgroup, 32 bytes
+    uint32_t lo;         // first row of the minibatch
+    uint32_t index;      // global minibatch index of the epoch: which sample ids
+    uint32_t kind;       // 0: program of rounds and jobs; 1: combine-tree nodes
+    uint32_t a, b, c, d; // program: first item, rounds, first job, jobs; nodes: first node of the minibatch, its nodes, this workgroup's index among their workgroups
+    uint32_t pad;
+};
+struct WideArgs {
+    StepArgs base;            // what all minibatches share; items / fin_items point at the launch's arrays
+    const WideDesc *wg;
+    const WJob *jobs;
+    const uint32_t *ids;      // the epoch's sample ids, `ids_stride` per minibatch
+    uint32_t ids_stride;
+};
+
+template <int OPT, int LPI, int NB, int U, bool FULL>
+__global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (OPT == 5 ? 4 : 3) : 1) void qwide_chain_kernel(const WideArgs w) {
+    constexpr uint32_t DP = 4u * LPI * NB, IPW = 64u / LPI, IPB = 4u * IPW;  // padded dims; lane groups per wavefront / workgroup
+    constexpr uint32_t PSLOTS = IPB > 32u ? IPB : 32u;                       // piece slots: one phase of rounds
+    constexpr uint32_t C4 = DP / 4u;                                          // 16-byte pieces per (padded) row
+    const WideDesc bd = w.wg[blockIdx.x];
+    StepArgs a = w.base;
+    a.batch_lo = bd.lo;
+    a.upd_rows = bd.lo - a.upd_lo;      // rows [upd_lo, this minibatch's first row) are read from the second matrix ...
+    a.chain_rows = bd.lo - a.chain_lo;  // ... those from chain_lo on after waiting for their flag
+#ifdef F2V_TEST_HOOKS
+    if (a.chain_lo == 0xFFFFFFFFu) a.chain_rows = 0u;  // f2v_test_chain_nowait
+#endif
+    a.sample_ids = w.ids + (size_t)bd.index * w.ids_stride;
+    const uint32_t D = FULL ? DP : a.D;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t t = lane & (LPI - 1u), q = lane / LPI;
+    if (bd.kind == 1u) {
+        constexpr int FVEC = DP >= 64u ? (int)(DP / 64u) : 1;
+        FinalizeTreeArgs ft;
+        ft.f.X = a.X; ft.f.partials = a.partials; ft.f.Xn = a.Xn; ft.f.items = a.fin_items + bd.a; ft.f.n_items = bd.b; ft.f.D = D;
+        ft.f.push = a.push;
+        ft.ready = a.ready; ft.err = a.err; ft.timeout_ticks = a.timeout_ticks; ft.seq = a.seq; ft.first_dep = 0u; ft.rowflag = a.rowflag;
+#ifdef F2V_TEST_HOOKS
+        ft.stamps = a.stamps;
+        ft.test_withhold_row = a.test_withhold_row;
+#endif
+        const uint32_t node = (uint32_t)__builtin_amdgcn_readfirstlane((int)(bd.c * 4u + wave));
+        finalize_tree_node<OPT, FVEC, (FULL && DP % 64u == 0u), true>(ft, node, lane);
+        return;
+    }
+
+    __shared__ float4 slots[PSLOTS + kWideSumSlots][C4];
+    constexpr uint32_t kLdsSamples = 8;
+    __shared__ float4 smp[kLdsSamples][C4];
+    __shared__ float sm_lds[OPT == 5 ? 1 : 2048];
+    __shared__ uint32_t wg_bad;  // a bounded wait of this workgroup gave up: nothing more is stored or announced
+    const bool lds_samples = !a.bs_mode && a.ns <= kLdsSamples;
+    if (threadIdx.x == 0) wg_bad = 0u;
+    if constexpr (OPT != 5) {
+        for (uint32_t k = threadIdx.x; k < 2048u; k += 256u) sm_lds[k] = a.sm_table[k];
+    }
+    bool smp_bad = false;
+    if (lds_samples) {
+        for (uint32_t k = threadIdx.x; k < a.ns * C4; k += 256u) {
+            const uint32_t sidx = k / C4, c4 = k % C4;
+            const uint32_t sj = a.sample_ids[sidx];
+            const bool handed = (sj - a.chain_lo) < a.chain_rows;
+            if (handed) smp_bad = wait_row(a, sj) || smp_bad;
+            const float *srow = row_src(a, sj, D);
+            smp[sidx][c4] = !(FULL || 4u * c4 < D) ? make_float4(0.f, 0.f, 0.f, 0.f) : handed ? load16_agent(srow + 4 * c4) : reinterpret_cast<const float4 *>(srow)[c4];
+        }
+    }
+    if (__syncthreads_or(smp_bad ? 1 : 0)) return;  // a sample row that never arrived: nobody stores
+    const float *table = OPT == 5 ? a.sm_table : sm_lds;
+
+    const Item *items = a.items + bd.a;
+    const WJob *jobs = w.jobs + bd.c;
+    const uint32_t n_jobs = bd.d;
+    uint32_t jc = 0;  // next job (uniform)
+
+    // the jobs of one phase: passes of up to 8 jobs, 32 lanes each; lane tl of a job owns the 16-byte pieces tl, tl + 32, ... of the row
+    auto run_jobs = [&](const uint32_t tag) {
+        const uint32_t team = threadIdx.x >> 5, tl = threadIdx.x & 31u;
+        while (jc < n_jobs) {
+            const WJob head = jobs[jc];
+            if (head.phase != tag) break;
+            const uint32_t len = head.pass_len;
+            if (team < len) {
+                const WJob jb = jobs[jc + team];
+                if (jb.kind == kJobImport) {
+                    // a helper's group sum: wait for its flag (bounded), then agent-scope loads into the LDS slot
+                    const unsigned long long t0 = wall_clock64();
+                    bool gave_up = false;
+                    uint32_t spins = 0;
+                    while (__hip_atomic_load(a.ready + jb.row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.seq) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if ((++spins & 15u) != 0u) continue;
+                        if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { gave_up = true; break; }
+                        if (wall_clock64() - t0 > a.timeout_ticks) {
+                            if (__hip_atomic_fetch_add(a.err + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                                a.err[2] = blockIdx.x; a.err[3] = jb.row; a.err[4] = a.ready[jb.row]; a.err[5] = a.seq; a.err[6] = gridDim.x; a.err[7] = a.batch_lo;
+                            }
+                            __hip_atomic_store(a.err, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            gave_up = true;
+                            break;
+                        }
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the poll has returned before the sum's loads are issued
+                    if (gave_up) {
+                        wg_bad = 1u;
+                    } else {
+                        const float *src = a.partials + (size_t)jb.row * D;
+                        for (uint32_t c = tl; 4u * c < D; c += 32u) slots[jb.dst][c] = load16_agent(src + 4u * c);
+                    }
+                } else {
+                    for (uint32_t c = tl; 4u * c < D; c += 32u) {
+                        float4 xi4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (OPT == 5 && jb.kind == kJobRow) xi4 = *reinterpret_cast<const float4 *>(a.X + (size_t)jb.row * D + 4u * c);
+                        float4 acc = slots[jb.src][c];
+                        for (uint32_t k = 1; k < jb.n; k += 8u) {  // 8 LDS reads in flight, added in slot order
+                            float4 p[8];
+#pragma unroll
+                            for (uint32_t u = 0; u < 8u; ++u) p[u] = slots[jb.src + (k + u < jb.n ? k + u : jb.n - 1u)][c];
+#pragma unroll
+                            for (uint32_t u = 0; u < 8u; ++u) {
+                                if (k + u < jb.n) { acc.x = acc.x + p[u].x; acc.y = acc.y + p[u].y; acc.z = acc.z + p[u].z; acc.w = acc.w + p[u].w; }
+                            }
+                        }
+                        if (jb.kind == kJobLds) {
+                            slots[jb.dst][c] = acc;
+                        } else if (jb.kind == kJobPart) {
+                            store16_agent(a.partials + (size_t)jb.dst * D + 4u * c, acc);
+                        } else {
+                            if constexpr (OPT == 5) acc = make_float4(xi4.x + acc.x, xi4.y + acc.y, xi4.z + acc.z, xi4.w + acc.w);  // algorithms.cpp:636
+                            store16_agent(a.Xn + (size_t)jb.row * D + 4u * c, acc);
+                        }
+                    }
+                    if (jb.kind != kJobLds) {
+                        __builtin_amdgcn_s_waitcnt(0);  // the written-through bytes have been acknowledged before they are announced
+                        if (tl == 0u) {
+                            if (jb.kind == kJobRow) {
+#ifdef F2V_TEST_HOOKS
+                                if (jb.row != a.test_withhold_row)  // fault injection: this row is never announced
+#endif
+                                __hip_atomic_store(a.rowflag + jb.row, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef F2V_TEST_HOOKS
+                                if (a.stamps) a.stamps[4 * (size_t)jb.row + 2] = wall_clock64();
+#endif
+                            } else {
+#ifdef F2V_TEST_HOOKS
+                                if (a.stamps) atomicMax(a.stamps + 4 * (size_t)jb.row + 1, wall_clock64());
+                                if (jb.dst != a.test_withhold_slot)  // fault injection: this sum is never announced
+#endif
+                                __hip_atomic_store(a.ready + jb.dst, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                        }
+                    }
+                }
+            }
+            jc += len;
+            __syncthreads();  // the pass's sums are in LDS (or announced); its source slots may be reused
+        }
+    };
+
+    if (n_jobs && jobs[0].phase == kJobBefore) {
+        run_jobs(kJobBefore);
+        if (wg_bad) return;
+    }
+    uint32_t phase = 0;
+    Item it = items[wave * IPW + q];
+    uint32_t jpre[U];  // the first ids of the current round's list, requested a round ago
+    {
+        const uint32_t cnt0 = (it.flags & kItemIdle) ? 0u : it.cnt;
+#pragma unroll
+        for (int u = 0; u < U; ++u) jpre[u] = ((uint32_t)u < cnt0) ? a.nbr_ids[it.nb + u] : 0u;
+    }
+    for (uint32_t r = 0; r < bd.b; ++r) {
+        Item itn;  // the next round's item: requested now, needed when this round's gathers are in flight
+        if (r + 1 < bd.b) itn = items[(r + 1) * IPB + wave * IPW + q];
+        else { itn.row = it.row; itn.nb = 0; itn.cnt = 0; itn.flags = kItemIdle; }
+        const bool idle = (it.flags & kItemIdle) != 0;
+        const bool direct = (it.flags & kItemDirect) != 0;
+        const bool first_chunk = (it.flags & kItemFirst) != 0;
+        const bool last_chunk = (it.flags & kItemLast) != 0;
+        const uint32_t row = it.row;
+        const uint32_t cnt = idle ? 0u : it.cnt;
+
+        float xi[NB][4], Y[NB][4];
+        {
+            const float *src = a.X + (size_t)row * D + t * 4;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const float4 v = (FULL || 4u * LPI * b + 4u * t < D) ? *reinterpret_cast<const float4 *>(src + 4 * LPI * b) : make_float4(0.f, 0.f, 0.f, 0.f);
+                xi[b][0] = v.x; xi[b][1] = v.y; xi[b][2] = v.z; xi[b][3] = v.w;
+            }
+        }
+        double c0 = 0.0;
+        if constexpr (OPT == 5) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) Y[b][v] = 0.0f;
+        } else {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) Y[b][v] = first_chunk ? xi[b][v] : 0.0f;
+            const uint32_t gdeg = a.rowptr[row + 1] - a.rowptr[row];
+            const float degi = (float)(1.0 / (double)(gdeg + 1u));  // algorithms.cpp:854
+            c0 = (double)(a.lr * degi);
+        }
+        bool bad = false;
+        qprocess_pre<OPT, LPI, NB, U, FULL>(a, a.nbr_ids + it.nb, cnt, wave_max_of_items<LPI>(cnt), t, D, xi, Y, c0, table, bad, jpre,
+                                            a.nbr_ids + itn.nb, (itn.flags & kItemIdle) ? 0u : itn.cnt);
+        if (lds_samples) {
+            if (!idle && last_chunk) {
+                for (uint32_t sidx = 0; sidx < a.ns; ++sidx) {
+                    float4 xs[NB];
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) xs[b] = smp[sidx][LPI * b + t];
+                    pair_update_q<OPT, LPI, NB, true>(xi, xs, Y, a.lr, c0, table);
+                }
+            }
+        } else {
+            const uint32_t scnt = (!idle && last_chunk) ? a.ns : 0u;
+            const uint32_t sbase = a.bs_mode ? (row - a.batch_lo) : 0u;
+            qprocess<OPT, LPI, NB, true, U, FULL, true>(a, a.sample_ids + sbase, scnt, wave_max_of_items<LPI>(scnt), t, D, xi, Y, c0, table, bad);
+        }
+        const bool wave_bad = __builtin_amdgcn_ballot_w64(bad) != 0ull;  // (wave-uniform: a wave stores all its items or none)
+        if (wave_bad) wg_bad = 1u;
+        if (!idle && !wave_bad) {
+            if (direct) {
+                float *out = a.Xn + (size_t)row * D + t * 4;
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    if (!FULL && !(4u * LPI * b + 4u * t < D)) continue;
+                    const float4 v = OPT == 5 ? make_float4(xi[b][0] + Y[b][0], xi[b][1] + Y[b][1], xi[b][2] + Y[b][2], xi[b][3] + Y[b][3])  // algorithms.cpp:636
+                                              : make_float4(Y[b][0], Y[b][1], Y[b][2], Y[b][3]);
+                    store16_agent(out + 4 * LPI * b, v);
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < NB; ++b) slots[it.flags & kItemPieceSlot][LPI * b + t] = make_float4(Y[b][0], Y[b][1], Y[b][2], Y[b][3]);
+#ifdef F2V_TEST_HOOKS
+                if (a.stamps && t == 0u) atomicMax(a.stamps + 4 * (size_t)row, wall_clock64());
+#endif
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(!idle && direct) != 0ull) {
+            __builtin_amdgcn_s_waitcnt(0);  // the wave's new rows are in memory before they are announced
+            if (!idle && direct && !wave_bad && t == 0u) {
+#ifdef F2V_TEST_HOOKS
+                if (row != a.test_withhold_row)
+#endif
+                __hip_atomic_store(a.rowflag + row, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef F2V_TEST_HOOKS
+                if (a.stamps) a.stamps[4 * (size_t)row + 2] = wall_clock64();
+#endif
+            }
+        }
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(it.flags & kItemPhaseEnd)) != 0u) {
+            if (jc < n_jobs && jobs[jc].phase == phase) {
+                __syncthreads();  // the phase's piece sums are in LDS
+                if (wg_bad) return;
+                run_jobs(phase);
+                if (wg_bad) return;
+            }
+            phase++;
+        }
+        it = itn;
+    }
 }
 
 // One level of the hub combine trees of a launch: every item adds up to `fanin` partial rows in

@@ -25,6 +25,9 @@ int f2v_test_gather_calibration(int device, uint32_t rows, uint32_t reps);
 /* Fault injection for the one-launch minibatch: the hub piece that owns partial-sum slot `slot` never announces its
  * sum (0xFFFFFFFF: none), so the combine-tree node that adds it has to give up its wait ("tree_timeout_ms"). */
 int f2v_test_withhold_flag(f2v_handle h, uint32_t slot);
+/* Fault injection for chained launches: the flag of `row` is never stored (0xFFFFFFFF: none), so every item of a later
+ * minibatch of the same launch that reads the row has to give up its wait ("chain_timeout_ms"). */
+int f2v_test_withhold_row(f2v_handle h, uint32_t row);
 /* Timing experiment: chained launches skip their row waits (the results are then WRONG): what the launch structure costs
  * without the dependency chain. */
 int f2v_test_chain_nowait(f2v_handle h, int on);

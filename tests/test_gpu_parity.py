@@ -194,7 +194,7 @@ def test_combine_tree_give_up_is_safe_reported_at_once_and_recoverable(F):
         with pytest.raises(F.F2VError) as ex:
             eng.train(5, 300, batch)
         msg = str(ex.value)
-        assert ex.value.code == _lib.F2V_ESTATE and "combine-tree waits gave up" in msg and "merge_finalize" in msg
+        assert ex.value.code == _lib.F2V_ESTATE and "gave up" in msg and "merge_finalize" in msg  # (tree-node waits, or the row waits behind them)
         noticed = int(re.search(r"noticed after epoch (\d+) of 300", msg).group(1))
         assert noticed <= 16, msg                                   # at once, not at the end of the run
         with pytest.raises(F.F2VError):                             # the embeddings are invalid until they are set again
@@ -234,7 +234,8 @@ def test_train_recovers_from_a_lost_launch(F, option, batch, bs):
         assert eng.get_param("recover") == 1
         if fault:
             eng.set_param("tree_timeout_ms", 1)
-            _lib.check(T.f2v_test_withhold_flag(eng._h, 0), T)
+            _lib.check(T.f2v_test_withhold_flag(eng._h, 0), T)   # a partial sum in HBM that is never announced ...
+            _lib.check(T.f2v_test_withhold_row(eng._h, 3), T)    # ... and, in chained launches, a hub row whose flag never comes
         eng.srand(1)
         eng.init_embeddings(0 if option == 5 else 1)
         eng.train(option, 40, batch, 5, 0.02, bs)
@@ -286,18 +287,20 @@ def test_two_handles_training_at_once_share_the_card_safely(F):
 
 
 def test_cli_survives_a_lost_launch(tmp_path):
-    """./bin/Force2Vec when a launch's in-grid waits give up (the self-test build preloaded in place of libf2v.so, one hub piece
-    never announcing, 1-ms bound): exit code 0 and the bytes of the healthy run -- through f2v_train's own snapshot, and, with
-    that switched off (F2V_RECOVER=0), through the rerun from the seed in algorithms::run."""
+    """The CLI when a launch's in-grid waits give up (bin/Force2Vec_selftest: the same cli_main.cpp linked with the self-test
+    build of the library; the flag of one row of the first minibatch never comes, 1-ms bound): exit code 0 and the bytes of the healthy run of
+    bin/Force2Vec -- through f2v_train's own snapshot, and, with that switched off (F2V_RECOVER=0), through the rerun from the
+    seed in algorithms::run."""
     exe = os.path.join(ROOT, "bin", "Force2Vec")
-    selftest = os.path.join(ROOT, "force2vec_amd", "libf2v_selftest.so")
+    rowptr, colids = O.read_mtx(golden_graph_path("cora.mtx"))
+    lost = next(i for i in range(256) if (colids[rowptr[i]:rowptr[i + 1]] >= 256).any())  # a row of the first minibatch that a later one reads: its flag never comes
     outs = {}
     for name, env_extra in (("healthy", {}),
-                            ("snapshot", {"LD_PRELOAD": selftest, "F2V_TEST_WITHHOLD_SLOT": "0", "F2V_TREE_TIMEOUT_MS": "1"}),
-                            ("rerun", {"LD_PRELOAD": selftest, "F2V_TEST_WITHHOLD_SLOT": "0", "F2V_TREE_TIMEOUT_MS": "1", "F2V_RECOVER": "0"})):
+                            ("snapshot", {"F2V_TEST_WITHHOLD_ROW": str(lost), "F2V_TREE_TIMEOUT_MS": "1"}),
+                            ("rerun", {"F2V_TEST_WITHHOLD_ROW": str(lost), "F2V_TREE_TIMEOUT_MS": "1", "F2V_RECOVER": "0"})):
         out = str(tmp_path / name) + "/"
         os.makedirs(out)
-        r = subprocess.run([exe, "-input", golden_graph_path("cora.mtx"), "-output", out, "-iter", "30", "-batch", "256", "-dim", "128", "-option", "5"],
+        r = subprocess.run([exe + ("_selftest" if env_extra else ""), "-input", golden_graph_path("cora.mtx"), "-output", out, "-iter", "30", "-batch", "256", "-dim", "128", "-option", "5"],
                            cwd=out, capture_output=True, text=True, timeout=300, env=dict(os.environ, **env_extra))
         assert r.returncode == 0, name + ": " + r.stdout + r.stderr
         outs[name] = open(out + "cora.mtxF2VNS256D128IT30NS5.embd", "rb").read()
