@@ -102,6 +102,7 @@ struct f2v_ctx {
     float *d_X[2] = {nullptr, nullptr}, *d_partials = nullptr, *d_table = nullptr;
     uint32_t *d_ready = nullptr, *d_kerr = nullptr;  // combine-tree flags (one per partial slot), kernel error word
     uint32_t launch_seq = 0;
+    bool launch_seq_wrapped = false;
     uint32_t xcc_count = 0;      // XCDs seen by the dispatch probe of f2v_create
     bool xcc_round_robin = false;  // ... and workgroup b ran on the XCD of workgroup b mod 8
     int64_t tree_timeout_ms = 5000;
@@ -115,6 +116,7 @@ struct f2v_ctx {
     uint32_t *h_kerr = nullptr;  // pinned: the kernel error words as of the last completed epoch-end copy (train_impl)
 #ifdef F2V_TEST_HOOKS
     uint32_t test_withhold_slot = kNoSlot, test_withhold_row = kNoSlot;
+    uint32_t test_chain_mode = 0;  // f2v_test_chain_nowait's argument as given (bit 0 = the old on/off)
     bool test_chain_nowait = false;  // timing experiment: chained launches without their row waits (results are then wrong)
     unsigned long long *d_stamps = nullptr;  // f2v_test_stamps: 4 wall-clock words per row (StepArgs::stamps)
 #endif
@@ -141,11 +143,17 @@ struct f2v_ctx {
     WJob *d_jobs = nullptr;
     size_t d_wide_cap = 0, d_wide_valid = 0, d_jobs_cap = 0, d_jobs_valid = 0;
     bool wide = true;
-    uint32_t wide_max_batch = 1024;  // larger chained minibatches are throughput-bound: they keep the HBM form (tools/wide_sweep.py)
-    uint32_t wide_phases = 2;   // phases (of 32 piece slots) a workgroup of small rows runs
-    uint32_t wide_span = 4;     // fan-in groups per helper workgroup
+    bool wide_poll2 = false;     // "chain_poll2": two polls of a row flag in flight
+    bool wide_mailbox = false;  // "chain_mailbox": rows handed on as data-tagged granules instead of flag + agent-scope loads
+    uint32_t wide_max_batch = 2048;  // larger chained minibatches are throughput-bound: they keep the HBM form (tools/wide_sweep.py)
+    uint32_t wide_rows = 262144;     // rows one launch of the wide form covers ("chain_rows" is the HBM form's)
+    uint32_t wide_order = 0;    // workgroups of a minibatch: 0 helpers, finishers, packed rows; 1 helpers, packed, finishers; 2 packed, helpers, finishers
+    uint32_t wide_phases = 1;   // phases (of 32 piece slots) a workgroup of small rows runs
+    uint32_t wide_span = 2;     // fan-in groups per helper workgroup
     uint32_t wide_finish = 4;   // fan-in groups the finisher workgroup keeps for itself (the ones that wait longest)
     uint32_t *d_rowflag = nullptr;  // per row: sequence number of the chained launch that last wrote it
+    unsigned long long *d_mailbox = nullptr;  // wide form: the launch's rows as data-tagged granules, chain_rows x D x 8 bytes (StepArgs::mailbox)
+    size_t mailbox_rows = 0;
     bool chain = true;            // "chain_batches"
     uint32_t chain_max_batch = 4096, chain_rows = 65536;  // measured on RMAT-20 (tools/small_batch.py, tools/chain_sweep.py)
     std::vector<Item> h_items;
@@ -483,8 +491,8 @@ const Plan &plan_for(f2v_ctx *c, uint32_t row_lo, uint32_t row_hi, bool walk) {
 }
 
 // Minibatches per chained launch ("chain_rows" rows per launch, at most 4096 minibatches)
-uint32_t chain_len(const f2v_ctx *c, uint32_t batch) {
-    const uint64_t k = (uint64_t)c->chain_rows / std::max(batch, 1u);
+uint32_t chain_len(const f2v_ctx *c, uint32_t batch, bool wide_form = false) {
+    const uint64_t k = (uint64_t)(wide_form ? c->wide_rows : c->chain_rows) / std::max(batch, 1u);
     return (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(k, 1));
 }
 
@@ -675,6 +683,11 @@ const WidePlan &wide_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t batc
         ph.clear();
     };
     auto slotted = [](Piece pc, size_t slot) { pc.it.flags |= (uint32_t)slot; return pc; };
+    auto mkjob = [](size_t src, uint32_t n, uint8_t kind, size_t phase, uint32_t dst, uint32_t row) {
+        WJob j{};
+        j.src = (uint8_t)src; j.n = (uint8_t)n; j.kind = kind; j.phase = (uint8_t)phase; j.dst = dst; j.row = row;
+        return j;
+    };
     // the jobs of one phase as passes of up to 8
     auto add_pass = [&](Prog &g, std::vector<WJob> &js) {
         for (size_t k = 0; k < js.size(); k += 8) {
@@ -769,7 +782,7 @@ const WidePlan &wide_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t batc
                     for (size_t h = h0; h < std::min(rest.size(), h0 + std::max(1u, c->wide_span)); h++) {
                         const Group &gr = groups[rest[h]];
                         if (ph.size() + gr.n > pslots) { close_phase(g, ph, lo); add_pass(g, js); }
-                        js.push_back(WJob{(uint16_t)ph.size(), (uint16_t)gr.n, kJobPart, (uint8_t)g.phases, 0, 0, l0_base + rest[h], i});
+                        js.push_back(mkjob(ph.size(), gr.n, kJobPart, g.phases, l0_base + rest[h], i));
                         for (uint32_t q = 0; q < gr.n; q++) ph.push_back(slotted(pieces[gr.first + q], ph.size()));
                     }
                     close_phase(g, ph, lo);
@@ -781,7 +794,7 @@ const WidePlan &wide_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t batc
                     Prog g;
                     std::vector<Piece> ph;
                     std::vector<WJob> js, imports;
-                    for (uint32_t r : rest) imports.push_back(WJob{0, 0, kJobImport, 0, 0, 0, pslots + r, l0_base + r});
+                    for (uint32_t r : rest) imports.push_back(mkjob(0, 0, kJobImport, 0, pslots + r, l0_base + r));
                     // phases of the own groups, in `own` order; the last phase starts with the last group that does not fit the one before
                     std::vector<std::vector<uint32_t>> phases(1);
                     {
@@ -799,13 +812,18 @@ const WidePlan &wide_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t batc
                         }
                         for (uint32_t g2 : phases[f]) {
                             const Group &gr = groups[g2];
-                            js.push_back(WJob{(uint16_t)ph.size(), (uint16_t)gr.n, kJobLds, (uint8_t)f, 0, 0, pslots + g2, i});
+                            js.push_back(mkjob(ph.size(), gr.n, kJobLds, f, pslots + g2, i));
                             for (uint32_t q = 0; q < gr.n; q++) ph.push_back(slotted(pieces[gr.first + q], ph.size()));
                         }
                         close_phase(g, ph, lo);
+                        if (f + 1 == phases.size() && js.size() == 1) break;  // the last phase's only group: added by the final job itself
                         add_pass(g, js);
                     }
-                    std::vector<WJob> fin{WJob{(uint16_t)pslots, (uint16_t)G, out_kind, (uint8_t)(phases.size() - 1), 0, 0, out_dst, i}};
+                    std::vector<WJob> fin{mkjob(pslots, G, out_kind, phases.size() - 1, out_dst, i)};
+                    if (js.size() == 1) {  // ... its pieces first (into its sum slot), then the groups' sums: one job, no barrier in between
+                        fin[0].src2 = js[0].src; fin[0].n2 = js[0].n; fin[0].dst2 = (uint8_t)js[0].dst;
+                        js.clear();
+                    }
                     add_pass(g, fin);
                     finishers.push_back(std::move(g));
                 }
@@ -836,7 +854,7 @@ const WidePlan &wide_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t batc
                         if (ph.size() + pk.n > pslots) continue;
                         taken[order[x]] = 1;
                         if (!(pieces[pk.first].it.flags & kItemDirect))
-                            js.push_back(WJob{(uint16_t)ph.size(), (uint16_t)pk.n, pk.kind, (uint8_t)f, 0, 0, pk.dst, pk.row});
+                            js.push_back(mkjob(ph.size(), pk.n, pk.kind, f, pk.dst, pk.row));
                         for (uint32_t q = 0; q < pk.n; q++) ph.push_back(slotted(pieces[pk.first + q], ph.size()));
                     }
                     while (head < order.size() && taken[order[head]]) head++;
@@ -868,9 +886,12 @@ const WidePlan &wide_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t batc
         p.n_helpers += (uint32_t)helpers.size();
         p.n_finishers += (uint32_t)finishers.size();
         p.n_packed += (uint32_t)packed.size();
+        // (a unit's helpers come before its finisher -- it waits for their sums; where the whole-row workgroups go is free)
+        if (c->wide_order == 2) emit(packed);
         emit(helpers);
+        if (c->wide_order == 1) emit(packed);
         emit(finishers);
-        emit(packed);
+        if (c->wide_order == 0) emit(packed);
         // the combine trees above the units of rows with more than F*F pieces, level by level
         const uint32_t fin_first = (uint32_t)(c->h_hubs.size() - p.fin_off);
         uint32_t fin_n = 0;
@@ -1363,15 +1384,25 @@ int launch_wide(f2v_ctx *c, int math, const WidePlan &plan, const uint32_t *d_id
     a.err = c->d_kerr;
     a.timeout_ticks = (unsigned long long)std::min(c->tree_timeout_ms, c->chain_timeout_ms) * 100000ull;
     a.seq = ++c->launch_seq;
-    if (a.seq == 0) a.seq = ++c->launch_seq;
+    if (a.seq == 0) { a.seq = ++c->launch_seq; c->launch_seq_wrapped = true; }
 #ifdef F2V_TEST_HOOKS
     a.test_withhold_slot = c->test_withhold_slot;
     a.test_withhold_row = c->test_withhold_row;
 #endif
     a.rowflag = c->d_rowflag;
     a.chain_lo = plan.lo;
+    // rows as tagged granules ("chain_mailbox"): not with -bs 1 / more than 8 samples, whose sample gathers use the flag protocol
+    const bool mb = c->wide_mailbox && !bs_mode && ns <= 8;
+    a.mailbox = mb ? c->d_mailbox : nullptr;
+    a.poll2 = c->wide_poll2 ? 1u : 0u;
+    if (mb && (size_t)(plan.hi - plan.lo) > c->mailbox_rows) return fail(F2V_ESTATE, "launch_wide: the launch covers more rows than the mailbox holds");
+    if (mb && a.seq == 1u && c->launch_seq_wrapped) {
+        // 2^32 launches later a tag could repeat: start from a clean mailbox (stream-ordered)
+        HIPC(hipMemsetAsync(c->d_mailbox, 0, c->mailbox_rows * c->D * sizeof(unsigned long long), c->stream));
+        c->launch_seq_wrapped = false;
+    }
 #ifdef F2V_TEST_HOOKS
-    if (c->test_chain_nowait) a.chain_lo = 0xFFFFFFFFu;
+    a.test_nowait = c->test_chain_mode;
     a.stamps = c->d_stamps;
 #endif
     wa.wg = c->d_wide + plan.wg_off;
@@ -1381,8 +1412,12 @@ int launch_wide(f2v_ctx *c, int math, const WidePlan &plan, const uint32_t *d_id
     const uint32_t width = subwave_width(c);
     const bool full = width == c->D;
     const int o = (math == 5) ? 5 : 6;
-#define F2V_W2(OPT, LPI, NB, U, FULL) hipLaunchKernelGGL((qwide_chain_kernel<OPT, LPI, NB, U, FULL>), dim3(plan.n_wgs), dim3(256), 0, c->stream, wa)
-#define F2V_W(OPT, LPI, NB, U) do { if (full) F2V_W2(OPT, LPI, NB, U, true); else F2V_W2(OPT, LPI, NB, U, false); } while (0)
+#define F2V_W2(OPT, LPI, NB, U, FULL, MB) hipLaunchKernelGGL((qwide_chain_kernel<OPT, LPI, NB, U, FULL, MB>), dim3(plan.n_wgs), dim3(256), 0, c->stream, wa)
+#define F2V_W(OPT, LPI, NB, U)                                                                        \
+    do {                                                                                              \
+        if (mb) { if (full) F2V_W2(OPT, LPI, NB, U, true, true); else F2V_W2(OPT, LPI, NB, U, false, true); }      \
+        else { if (full) F2V_W2(OPT, LPI, NB, U, true, false); else F2V_W2(OPT, LPI, NB, U, false, false); }       \
+    } while (0)
     switch (width) {
         case 32: if (o == 5) F2V_W(5, 8, 1, 8); else F2V_W(6, 8, 1, 8); break;
         case 64: if (o == 5) F2V_W(5, 16, 1, 8); else F2V_W(6, 16, 1, 8); break;
@@ -1695,7 +1730,7 @@ int f2v_destroy(f2v_handle c) {
     (void)hipSetDevice(c->device);
     (void)push_detach(c);
     void *ptrs[] = {c->d_rowptr, c->d_colids, c->d_walks, c->d_walks_alt, c->d_ids, c->d_X[0], c->d_X[1],
-                    c->d_partials, c->d_table, c->d_items, c->d_hubs, c->d_ready, c->d_kerr, c->d_wg, c->d_rowflag, c->d_snap, c->d_wide, c->d_jobs, c->push.flags, c->push.d_err, c->push.d_masks, c->push.d_patch, c->push.landing_buf};
+                    c->d_partials, c->d_table, c->d_items, c->d_hubs, c->d_ready, c->d_kerr, c->d_wg, c->d_rowflag, c->d_snap, c->d_wide, c->d_jobs, c->d_mailbox, c->push.flags, c->push.d_err, c->push.d_masks, c->push.d_patch, c->push.landing_buf};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 #ifdef F2V_TEST_HOOKS
@@ -1922,13 +1957,23 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
         c->wide_max_batch = (uint32_t)value;
         return F2V_OK;
     }
+    if (!strcmp(name, "wide_rows")) {
+        if (value < 2 || value > 0x7FFFFFFFll) return fail(F2V_EINVAL, "wide_rows out of range");
+        HIPC(hipSetDevice(c->device));
+        int rc = flush_pending(c);
+        if (rc != F2V_OK) return rc;
+        HIPC(hipStreamSynchronize(c->stream));
+        c->wide_rows = (uint32_t)value;
+        drop_plans(c);
+        return F2V_OK;
+    }
     if (!strcmp(name, "chain_rows")) {  // rows one chained launch covers
         if (value < 2 || value > 0x7FFFFFFFll) return fail(F2V_EINVAL, "chain_rows out of range");
         HIPC(hipSetDevice(c->device));
         int rc = flush_pending(c);
         if (rc != F2V_OK) return rc;
         HIPC(hipStreamSynchronize(c->stream));
-        c->chain_rows = (uint32_t)value;
+        c->chain_rows = c->wide_rows = (uint32_t)value;  // an explicit value holds for both forms ("wide_rows" alone: the wide form's)
         drop_plans(c);
         return F2V_OK;
     }
@@ -1937,8 +1982,17 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
         c->tree_timeout_ms = value;
         return F2V_OK;
     }
-    if (!strcmp(name, "chain_wide") || !strcmp(name, "wide_phases") || !strcmp(name, "wide_span") || !strcmp(name, "wide_finish")) {
-        if (name[0] == 'w' && (value < 1 || value > 64)) return fail(F2V_EINVAL, "%s must be 1..64", name);
+    if (!strcmp(name, "chain_mailbox")) {
+        c->wide_mailbox = value != 0;
+        return F2V_OK;
+    }
+    if (!strcmp(name, "chain_poll2")) {
+        c->wide_poll2 = value != 0;
+        return F2V_OK;
+    }
+    if (!strcmp(name, "chain_wide") || !strcmp(name, "wide_phases") || !strcmp(name, "wide_span") || !strcmp(name, "wide_finish") || !strcmp(name, "wide_order")) {
+        if (name[0] == 'w' && strcmp(name, "wide_order") && (value < 1 || value > 64)) return fail(F2V_EINVAL, "%s must be 1..64", name);
+        if (!strcmp(name, "wide_order") && (value < 0 || value > 2)) return fail(F2V_EINVAL, "wide_order must be 0, 1 or 2");
         HIPC(hipSetDevice(c->device));
         int rc = flush_pending(c);
         if (rc != F2V_OK) return rc;
@@ -1946,6 +2000,7 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
         if (!strcmp(name, "chain_wide")) c->wide = value != 0;
         else if (!strcmp(name, "wide_phases")) c->wide_phases = (uint32_t)value;
         else if (!strcmp(name, "wide_span")) c->wide_span = (uint32_t)value;
+        else if (!strcmp(name, "wide_order")) c->wide_order = (uint32_t)value;
         else c->wide_finish = (uint32_t)value;
         drop_plans(c);
         return F2V_OK;
@@ -2003,9 +2058,13 @@ int f2v_get_param(f2v_handle c, const char *name, int64_t *out) {
     if (!strcmp(name, "chain_batches")) { *out = c->chain ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "chain_timeout_ms")) { *out = c->chain_timeout_ms; return F2V_OK; }
     if (!strcmp(name, "chain_wide")) { *out = c->wide ? 1 : 0; return F2V_OK; }
+    if (!strcmp(name, "chain_mailbox")) { *out = c->wide_mailbox ? 1 : 0; return F2V_OK; }
+    if (!strcmp(name, "chain_poll2")) { *out = c->wide_poll2 ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "wide_phases")) { *out = c->wide_phases; return F2V_OK; }
     if (!strcmp(name, "wide_max_batch")) { *out = c->wide_max_batch; return F2V_OK; }
+    if (!strcmp(name, "wide_rows")) { *out = c->wide_rows; return F2V_OK; }
     if (!strcmp(name, "wide_span")) { *out = c->wide_span; return F2V_OK; }
+    if (!strcmp(name, "wide_order")) { *out = c->wide_order; return F2V_OK; }
     if (!strcmp(name, "wide_finish")) { *out = c->wide_finish; return F2V_OK; }
     if (!strcmp(name, "last_train_form")) { *out = c->last_train_form; return F2V_OK; }
     if (!strcmp(name, "recover")) { *out = c->recover ? 1 : 0; return F2V_OK; }
@@ -2300,8 +2359,8 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
     const bool all_upfront = (math != 7 || c->fast_rng) && (per_epoch * iters * 4ull <= (1ull << 30));
     // small minibatches: groups of them in one launch (chain_plan_for), ordered by data dependencies instead of launch boundaries
     const bool chained = iters > 0 && chain_usable(c, math, batch, bs_mode, sharded);
-    const bool wide = chained && wide_usable(c) && batch <= c->wide_max_batch;
-    const uint32_t K = chained ? chain_len(c, batch) : 1;
+    const bool wide = chained && wide_usable(c) && batch <= c->wide_max_batch && chain_len(c, batch, true) >= 2;
+    const uint32_t K = chained ? chain_len(c, batch, wide) : 1;
     c->last_train_form = wide ? 2 : chained ? 1 : 0;
     if (wide) {
         for (uint32_t b0 = 0; b0 < nb; b0 += K) (void)wide_plan_for(c, b0, std::min(K, nb - b0), batch, math == 7);
@@ -2335,6 +2394,19 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
             }
         }
     };
+    if (wide && c->wide_mailbox) {
+        const size_t rows = std::min<size_t>((size_t)K * batch, c->n);
+        if (rows > c->mailbox_rows) {
+            HIPC(hipStreamSynchronize(c->stream));
+            if (c->d_mailbox) (void)hipFree(c->d_mailbox);
+            c->d_mailbox = nullptr;
+            c->mailbox_rows = 0;
+            HIPC(hipMalloc((void **)&c->d_mailbox, rows * c->D * sizeof(unsigned long long)));
+            HIPC(hipMemsetAsync(c->d_mailbox, 0, rows * c->D * sizeof(unsigned long long), c->stream));  // 0 is no launch's sequence number
+            HIPC(hipStreamSynchronize(c->stream));
+            c->mailbox_rows = rows;
+        }
+    }
     if (chained && !c->d_rowflag) {
         HIPC(hipMalloc((void **)&c->d_rowflag, (size_t)c->n * sizeof(uint32_t)));
         HIPC(hipMemsetAsync(c->d_rowflag, 0, (size_t)c->n * sizeof(uint32_t), c->stream));  // 0 is no launch's sequence number
@@ -2756,7 +2828,8 @@ int f2v_test_withhold_row(f2v_handle c, uint32_t row) {
 
 int f2v_test_chain_nowait(f2v_handle c, int on) {
     if (!c) return fail(F2V_EINVAL, "null handle");
-    c->test_chain_nowait = on != 0;
+    c->test_chain_nowait = (on & 1) != 0;
+    c->test_chain_mode = (uint32_t)on;
     return F2V_OK;
 }
 

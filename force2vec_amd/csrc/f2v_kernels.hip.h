@@ -108,12 +108,17 @@ struct StepArgs {
     // this very launch; a reader waits until rowflag[row] == seq before it loads one of them
     uint32_t *rowflag;
     uint32_t chain_lo, chain_rows;
+    // wide form: row r of the launch is ALSO written as D data-tagged 8-byte granules {float, seq} at mailbox[(r - chain_lo) * D + d];
+    // readers of later minibatches poll the granules themselves (no flag, no acknowledgement in between)
+    unsigned long long *mailbox;
+    uint32_t poll2;  // wide form: waits keep two polls of a row flag in flight, half a round trip apart ("chain_poll2")
 #ifdef F2V_TEST_HOOKS
     uint32_t test_withhold_slot;      // f2v_test_withhold_flag: the piece with this partial slot never announces (kNoSlot: none)
     // f2v_test_stamps: per row four 100-MHz wall-clock words -- [0] its last hub piece announced, [1] its last inner tree node
     // announced, [2] its row flag stored, [3] ~(first time a waiter that had to wait saw that flag); nullptr: off
     unsigned long long *stamps;
     uint32_t test_withhold_row;       // f2v_test_withhold_row: chained launches never store this row's flag (kNoSlot: none)
+    uint32_t test_nowait;             // f2v_test_chain_nowait (wide form): no row of the launch is waited for
 #endif
 };
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
@@ -475,6 +480,8 @@ struct FinalizeTreeArgs {
     unsigned long long timeout_ticks;
     uint32_t seq;
     uint32_t first_dep;       // items from this index on add sums produced INSIDE this launch
+    unsigned long long *mailbox;  // wide form: the root also writes the row's tagged granules (StepArgs::mailbox)
+    uint32_t chain_lo;
 #ifdef F2V_TEST_HOOKS
     unsigned long long *stamps;
     uint32_t test_withhold_row;
@@ -605,6 +612,24 @@ __device__ __forceinline__ void finalize_tree_node(const FinalizeTreeArgs &a, ui
             for (int v = 0; v < VEC; ++v) Y[v] = xi[v] + Y[v];
         }
         if constexpr (ROW_THROUGH) {
+            if (a.mailbox) {
+                // wide form: the row for later launches (plain store) and its tagged granules for later minibatches of this one
+                store_row<VEC, EXACT>(f.Xn + (size_t)h.row * D, lane, D, Y);
+#ifdef F2V_TEST_HOOKS
+                if (h.row == a.test_withhold_row) return;  // fault injection: this row never arrives
+#endif
+                unsigned long long *g = a.mailbox + (size_t)(h.row - a.chain_lo) * D;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const uint32_t d = lane * VEC + v;
+                    if (EXACT || d < D)
+                        __hip_atomic_store(g + d, ((unsigned long long)a.seq << 32) | (unsigned long long)__builtin_bit_cast(uint32_t, Y[v]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#ifdef F2V_TEST_HOOKS
+                if (a.stamps && lane == 0) a.stamps[4 * (size_t)h.row + 2] = wall_clock64();
+#endif
+                return;
+            }
             store_row_agent<VEC, EXACT>(f.Xn + (size_t)h.row * D, lane, D, Y);
             __builtin_amdgcn_s_waitcnt(0);  // the row is in memory before it is announced
 #ifdef F2V_TEST_HOOKS
@@ -755,9 +780,37 @@ __device__ __forceinline__ bool wait_row_slow(const StepArgs &a, uint32_t j) {
     }
 }
 
+// The same wait with TWO polls in flight, half a round trip apart: a flag that has just been stored is seen a quarter of a
+// round trip later on average instead of half of one (the wait sits on every hop of the dependency chain).
+__device__ __forceinline__ bool wait_row_slow2(const StepArgs &a, uint32_t j) {
+    const uint32_t *f = a.rowflag + j;
+    const unsigned long long t0 = wall_clock64();
+    uint32_t v0 = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_sleep(6);
+    for (uint32_t spins = 1;; ++spins) {
+        const uint32_t v1 = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // issued before the older poll is looked at
+        if (v0 == a.seq) {
+#ifdef F2V_TEST_HOOKS
+            if (a.stamps) atomicMax(a.stamps + 4 * (size_t)j + 3, ~wall_clock64());
+#endif
+            return false;
+        }
+        v0 = v1;
+        if ((spins & 31u) != 0u) continue;
+        if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return true;
+        if (wall_clock64() - t0 > a.timeout_ticks) {
+            if (__hip_atomic_fetch_add(a.err + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                a.err[2] = blockIdx.x; a.err[3] = j; a.err[4] = *f; a.err[5] = a.seq; a.err[6] = gridDim.x; a.err[7] = a.batch_lo;
+            }
+            __hip_atomic_store(a.err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return true;
+        }
+    }
+}
+
 __device__ __forceinline__ bool wait_row(const StepArgs &a, uint32_t j) {
     bool bad = false;
-    if (__hip_atomic_load(a.rowflag + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.seq) bad = wait_row_slow(a, j);
+    if (__hip_atomic_load(a.rowflag + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.seq) bad = a.poll2 ? wait_row_slow2(a, j) : wait_row_slow(a, j);
     asm volatile("" ::: "memory");  // the row's loads stay behind the poll
     return bad;
 }
@@ -817,39 +870,140 @@ __device__ __forceinline__ void qprocess(const StepArgs &a, const uint32_t *ids,
     }
 }
 
+// ---- data-tagged granules (wide form) --------------------------------------------------------------------------------
+// A row handed from one minibatch to a later one of the same launch travels as 8-byte granules {float, seq} (seq = the
+// launch's sequence number: no other launch ever wrote that value into the mailbox), each written by one written-through
+// store (two granules per 16-byte sc1 store; its 8-byte halves are not torn -- MI355X_MICROARCH.md, R2's granule) and read by
+// agent-scope loads: a granule whose tag matches carries its float, whatever else is in flight -- no acknowledgement wait and
+// no flag on the writer's side, ONE round trip instead of poll-then-load on the reader's.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mailbox_store4(unsigned long long *g, const float4 v, uint32_t seq) {  // granules of 4 consecutive dims
+    const u32x4_t lo = {__builtin_bit_cast(uint32_t, v.x), seq, __builtin_bit_cast(uint32_t, v.y), seq};
+    const u32x4_t hi = {__builtin_bit_cast(uint32_t, v.z), seq, __builtin_bit_cast(uint32_t, v.w), seq};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(g), "v"(lo) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(g + 2), "v"(hi) : "memory");
+}
+
+// dims [dim0, dim0 + 4) of every block (4*LPI dims apart) of row j, once all their tags say `seq`.  -> true: gave up.
+template <int LPI, int NB, bool FULL>
+__device__ __forceinline__ bool mailbox_read(const StepArgs &a, uint32_t j, uint32_t dim0, uint32_t D, float4 (&out)[NB]) {
+    const unsigned long long *g = a.mailbox + ((size_t)(j - a.chain_lo) * D + dim0);
+    unsigned long long t0 = 0;
+    for (uint32_t spins = 0;; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (!(FULL || 4u * LPI * b + dim0 < D)) { out[b] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+            const unsigned long long *q = g + 4 * LPI * b;
+            const unsigned long long g0 = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long g1 = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long g2 = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long g3 = __hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = ok && (uint32_t)(g0 >> 32) == a.seq && (uint32_t)(g1 >> 32) == a.seq && (uint32_t)(g2 >> 32) == a.seq && (uint32_t)(g3 >> 32) == a.seq;
+            out[b] = make_float4(__builtin_bit_cast(float, (uint32_t)g0), __builtin_bit_cast(float, (uint32_t)g1),
+                                 __builtin_bit_cast(float, (uint32_t)g2), __builtin_bit_cast(float, (uint32_t)g3));
+        }
+        if (ok) {
+#ifdef F2V_TEST_HOOKS
+            if (a.stamps && spins) atomicMax(a.stamps + 4 * (size_t)j + 3, ~wall_clock64());
+#endif
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(2);
+        if ((spins & 15u) != 15u) continue;
+        if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return true;
+        const unsigned long long now = wall_clock64();
+        if (t0 == 0) { t0 = now; continue; }
+        if (now - t0 > a.timeout_ticks) {
+            // err[0] code 3, [1] how many waits timed out, [2..7] the first: waiting workgroup, row, tag seen, seq, grid, minibatch's first row
+            if (__hip_atomic_fetch_add(a.err + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                a.err[2] = blockIdx.x; a.err[3] = j; a.err[4] = (uint32_t)(*g >> 32); a.err[5] = a.seq; a.err[6] = gridDim.x; a.err[7] = a.batch_lo;
+            }
+            __hip_atomic_store(a.err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return true;
+        }
+    }
+}
+
 // The same walk for the rounds of a wide program (always a chained launch, always attracting neighbours): the first U ids of
 // the list arrive in `j` (loaded a round ago), and once the list's last gathers have been issued the first U ids of the NEXT
 // round's list are requested into `j` -- behind the gathers, so that waiting for the rows does not wait for them.  A round
 // then costs one memory latency (the rows) instead of three dependent ones (item, ids, rows).
-template <int OPT, int LPI, int NB, int U, bool FULL>
+template <int OPT, int LPI, int NB, int U, bool FULL, bool MB>
 __device__ __forceinline__ void qprocess_pre(const StepArgs &a, const uint32_t *ids, uint32_t cnt, uint32_t maxcnt, uint32_t t, uint32_t D,
                                              const float (&xi)[NB][4], float (&Y)[NB][4], double c0, const float *table, bool &bad,
                                              uint32_t (&j)[U], const uint32_t *next_ids, uint32_t next_cnt) {
     uint32_t g = 0;
     do {
         float4 xj[U][NB];
+        bool handed[U];
+        uint32_t fl[U];
+        // rows written inside this launch: ALL their flags are requested first (side by side, behind nothing) ...
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (g + u < cnt) {
-                const bool handed = (j[u] - a.chain_lo) < a.chain_rows;
-                if (handed) bad = wait_row(a, j[u]) || bad;
+            handed[u] = (g + u < cnt) && (j[u] - a.chain_lo) < a.chain_rows;
+            fl[u] = 0u;
+            if (!MB && handed[u]) fl[u] = __hip_atomic_load(a.rowflag + j[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // ... then the rows that need no wait ...
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (g + u < cnt && !handed[u]) {
                 const float *src = row_src(a, j[u], D) + t * 4;
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
                     if (!(FULL || 4u * LPI * b + 4u * t < D)) xj[u][b] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    else if (handed) xj[u][b] = load16_agent(src + 4 * LPI * b);
                     else xj[u][b] = *reinterpret_cast<const float4 *>(src + 4 * LPI * b);
                 }
             }
         }
+        uint32_t j0[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) j0[u] = j[u];
         const bool last = g + U >= maxcnt;  // (uniform)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (last) j[u] = ((uint32_t)u < next_cnt) ? next_ids[u] : 0u;
             else j[u] = (g + U + u < cnt) ? ids[g + U + u] : 0u;
         }
+        // ... then, side by side again, every handed row whose flag was already up (most: they were written minibatches ago)
+        if constexpr (!MB) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (handed[u] && fl[u] == a.seq) {
+                    asm volatile("" ::: "memory");  // the row's loads stay behind the poll
+                    const float *src = a.Xn + (size_t)j0[u] * D + t * 4;
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        if (!(FULL || 4u * LPI * b + 4u * t < D)) xj[u][b] = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef F2V_TEST_HOOKS
+                        else if (a.test_nowait & 4u) xj[u][b] = *reinterpret_cast<const float4 *>(src + 4 * LPI * b);
+#endif
+                        else xj[u][b] = load16_agent(src + 4 * LPI * b);
+                    }
+                    handed[u] = false;
+                }
+            }
+        }
+        // the interactions in list order; a row that has not been announced yet is awaited just before its own
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            if (handed[u]) {
+                if constexpr (MB) {
+                    bad = mailbox_read<LPI, NB, FULL>(a, j0[u], 4u * t, D, xj[u]) || bad;
+                } else {
+                    bad = wait_row(a, j0[u]) || bad;  // its flag, then agent-scope loads
+                    const float *src = a.Xn + (size_t)j0[u] * D + t * 4;
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        if (!(FULL || 4u * LPI * b + 4u * t < D)) xj[u][b] = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef F2V_TEST_HOOKS
+                        else if (a.test_nowait & 4u) xj[u][b] = *reinterpret_cast<const float4 *>(src + 4 * LPI * b);
+#endif
+                        else xj[u][b] = load16_agent(src + 4 * LPI * b);
+                    }
+                }
+            }
             if (g + u < cnt) pair_update_q<OPT, LPI, NB, false>(xi, xj[u], Y, a.lr, c0, table);
         }
         g += U;
@@ -886,6 +1040,7 @@ __device__ __forceinline__ void qstep_body(const StepArgs &a, const uint32_t blk
         ft.f.X = a.X; ft.f.partials = a.partials; ft.f.Xn = a.Xn; ft.f.items = a.fin_items; ft.f.n_items = a.fin_n; ft.f.D = D;
         ft.f.push = a.push;
         ft.ready = a.ready; ft.err = a.err; ft.timeout_ticks = a.timeout_ticks; ft.seq = a.seq; ft.first_dep = 0u; ft.rowflag = a.rowflag;
+        ft.mailbox = a.mailbox; ft.chain_lo = a.chain_lo;
 #ifdef F2V_TEST_HOOKS
         ft.stamps = a.stamps;
         ft.test_withhold_row = a.test_withhold_row;
@@ -1130,14 +1285,16 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? 5 : 1) void qstep_chain_
 //   * rows of more than fanin^2 pieces keep combine-tree nodes for the levels above their units' sums (finalize_tree_node).
 // Waits only ever point at smaller workgroup indices (rows of earlier minibatches; a unit's helpers), as before.
 struct WJob {            // 16 bytes
-    uint16_t src, n;     // LDS slots [src, src + n) are added in order (kJobImport: unused)
+    uint8_t src, n;      // LDS slots [src, src + n) are added in order (kJobImport: unused)
     uint8_t kind;        // kJob*
     uint8_t phase;       // the job runs when this phase of the workgroup's program has ended (kJobBefore: before the first round)
     uint8_t pass_len;    // jobs [this, this + pass_len) run side by side (<= 8): set on every job of the pass
-    uint8_t pad;
+    uint8_t src2, n2;    // n2 != 0: first LDS slots [src2, src2 + n2) are added in order into LDS slot `dst2` (one of [src, src + n)):
+    uint8_t dst2;        //          the last fan-in group's sum and the sum of the groups' sums in ONE job of one 32-lane team
     uint32_t dst;        // kJobLds, kJobImport: LDS slot; kJobPart: partial-sum slot in HBM
     uint32_t row;        // kJobRow / kJobPart: the row; kJobImport: the partial-sum slot in HBM that is fetched
 };
+static_assert(sizeof(WJob) == 16, "job descriptor layout");
 constexpr uint8_t kJobLds = 0, kJobPart = 1, kJobRow = 2, kJobImport = 3;
 constexpr uint8_t kJobBefore = 255;
 constexpr uint32_t kItemDirect = 1u << 28;    // wide programs: a whole row -- its new embedding is stored by the item itself
@@ -1161,7 +1318,14 @@ struct WideArgs {
     uint32_t ids_stride;
 };
 
-template <int OPT, int LPI, int NB, int U, bool FULL>
+// a workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global load and store of the wave
+// (the next round's prefetched item and ids, written-through rows on their way) -- none of which the other waves need
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+constexpr uint32_t kWideJobsLds = 64;  // a workgroup's first jobs are staged in LDS when it starts (more stay in global memory)
+
+// MB: rows travel to later minibatches of the launch as data-tagged granules (StepArgs::mailbox) instead of flag + agent-scope loads
+template <int OPT, int LPI, int NB, int U, bool FULL, bool MB>
 __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (OPT == 5 ? 4 : 3) : 1) void qwide_chain_kernel(const WideArgs w) {
     constexpr uint32_t DP = 4u * LPI * NB, IPW = 64u / LPI, IPB = 4u * IPW;  // padded dims; lane groups per wavefront / workgroup
     constexpr uint32_t PSLOTS = IPB > 32u ? IPB : 32u;                       // piece slots: one phase of rounds
@@ -1172,7 +1336,7 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (OPT == 5 ? 4 : 3) : 1) 
     a.upd_rows = bd.lo - a.upd_lo;      // rows [upd_lo, this minibatch's first row) are read from the second matrix ...
     a.chain_rows = bd.lo - a.chain_lo;  // ... those from chain_lo on after waiting for their flag
 #ifdef F2V_TEST_HOOKS
-    if (a.chain_lo == 0xFFFFFFFFu) a.chain_rows = 0u;  // f2v_test_chain_nowait
+    if (a.test_nowait & 1u) a.chain_rows = 0u;  // f2v_test_chain_nowait (further bits: timing experiments, results WRONG)
 #endif
     a.sample_ids = w.ids + (size_t)bd.index * w.ids_stride;
     const uint32_t D = FULL ? DP : a.D;
@@ -1184,6 +1348,7 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (OPT == 5 ? 4 : 3) : 1) 
         ft.f.X = a.X; ft.f.partials = a.partials; ft.f.Xn = a.Xn; ft.f.items = a.fin_items + bd.a; ft.f.n_items = bd.b; ft.f.D = D;
         ft.f.push = a.push;
         ft.ready = a.ready; ft.err = a.err; ft.timeout_ticks = a.timeout_ticks; ft.seq = a.seq; ft.first_dep = 0u; ft.rowflag = a.rowflag;
+        ft.mailbox = MB ? a.mailbox : nullptr; ft.chain_lo = a.chain_lo;
 #ifdef F2V_TEST_HOOKS
         ft.stamps = a.stamps;
         ft.test_withhold_row = a.test_withhold_row;
@@ -1208,29 +1373,130 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (OPT == 5 ? 4 : 3) : 1) 
         for (uint32_t k = threadIdx.x; k < a.ns * C4; k += 256u) {
             const uint32_t sidx = k / C4, c4 = k % C4;
             const uint32_t sj = a.sample_ids[sidx];
-            const bool handed = (sj - a.chain_lo) < a.chain_rows;
-            if (handed) smp_bad = wait_row(a, sj) || smp_bad;
-            const float *srow = row_src(a, sj, D);
-            smp[sidx][c4] = !(FULL || 4u * c4 < D) ? make_float4(0.f, 0.f, 0.f, 0.f) : handed ? load16_agent(srow + 4 * c4) : reinterpret_cast<const float4 *>(srow)[c4];
+            if (!(FULL || 4u * c4 < D)) {
+                smp[sidx][c4] = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else if ((sj - a.chain_lo) < a.chain_rows) {  // written inside this launch
+                if constexpr (MB) {  // its tagged granules (c4 as a one-lane group of block 0)
+                    float4 v[1];
+                    smp_bad = mailbox_read<1, 1, true>(a, sj, 4u * c4, D, v) || smp_bad;
+                    smp[sidx][c4] = v[0];
+                } else {
+                    smp_bad = wait_row(a, sj) || smp_bad;
+                    smp[sidx][c4] = load16_agent(row_src(a, sj, D) + 4 * c4);
+                }
+            } else {
+                smp[sidx][c4] = reinterpret_cast<const float4 *>(row_src(a, sj, D))[c4];
+            }
         }
     }
-    if (__syncthreads_or(smp_bad ? 1 : 0)) return;  // a sample row that never arrived: nobody stores
     const float *table = OPT == 5 ? a.sm_table : sm_lds;
 
     const Item *items = a.items + bd.a;
-    const WJob *jobs = w.jobs + bd.c;
+    const WJob *gjobs = w.jobs + bd.c;
     const uint32_t n_jobs = bd.d;
     uint32_t jc = 0;  // next job (uniform)
+    // (the jobs run at the end of the dependency chain's hops: their descriptors wait in LDS, not behind two more global loads)
+    __shared__ WJob ljobs[kWideJobsLds];
+    if (threadIdx.x < n_jobs && threadIdx.x < kWideJobsLds) ljobs[threadIdx.x] = gjobs[threadIdx.x];
+    auto job_at = [&](uint32_t k) -> WJob { return k < kWideJobsLds ? ljobs[k] : gjobs[k]; };
+    if (__syncthreads_or(smp_bad ? 1 : 0)) return;  // a sample row that never arrived: nobody stores
+    // the workgroup's last job, when it finishes a row alone in its pass (a finisher's): x_i is requested now, not at the end of the hop
+    float xi_pre = 0.f;
+    uint32_t xi_pre_for = 0xFFFFFFFFu;
+    if (OPT == 5 && n_jobs != 0u) {
+        const WJob jl = job_at(n_jobs - 1u);
+        if (jl.kind == kJobRow && jl.pass_len == 1u) {
+            xi_pre_for = n_jobs - 1u;
+            if (threadIdx.x < D) xi_pre = a.X[(size_t)jl.row * D + threadIdx.x];
+        }
+    }
 
     // the jobs of one phase: passes of up to 8 jobs, 32 lanes each; lane tl of a job owns the 16-byte pieces tl, tl + 32, ... of the row
     auto run_jobs = [&](const uint32_t tag) {
         const uint32_t team = threadIdx.x >> 5, tl = threadIdx.x & 31u;
         while (jc < n_jobs) {
-            const WJob head = jobs[jc];
+            const WJob head = job_at(jc);
             if (head.phase != tag) break;
             const uint32_t len = head.pass_len;
+            if (len == 1u && head.kind != kJobImport) {
+                // A job alone in its pass (a whole fan-in group's sum, a unit's sum: the long ones, at the end of a hop of the
+                // dependency chain) runs on ALL threads, one dim each: every slot read is issued before the first addition, the
+                // additions are one dependent chain of n instead of four interleaved ones (MI355X: ~0.5 us -> ~0.2 us for 32 slots).
+                const WJob jb = head;
+                const uint32_t d = threadIdx.x;
+                float *S = reinterpret_cast<float *>(&slots[0][0]);
+                auto sum32 = [&](uint32_t first, uint32_t n) -> float {
+                    float v[32];
+#pragma unroll
+                    for (uint32_t k = 0; k < 32u; ++k) v[k] = S[(size_t)(first + (k < n ? k : n - 1u)) * DP + d];
+                    float acc = v[0];
+#pragma unroll
+                    for (uint32_t k = 1; k < 32u; ++k) acc = (k < n) ? acc + v[k] : acc;
+                    return acc;
+                };
+                if (d < D) {  // (D is a multiple of 32 in chained launches: a wavefront's quads are live or idle as a whole)
+                    float xi1 = 0.f;
+                    if (OPT == 5 && jb.kind == kJobRow) xi1 = (xi_pre_for == jc) ? xi_pre : a.X[(size_t)jb.row * D + d];
+#ifdef F2V_TEST_HOOKS
+                    const bool skip_sums = (a.test_nowait & 8u) != 0u;
+#else
+                    constexpr bool skip_sums = false;
+#endif
+                    if (jb.n2 != 0u && !skip_sums) S[(size_t)jb.dst2 * DP + d] = sum32(jb.src2, jb.n2);  // (read back by this very lane below)
+                    float acc = sum32(jb.src, skip_sums ? 1u : jb.n);
+                    if (jb.kind == kJobLds) {
+                        S[(size_t)jb.dst * DP + d] = acc;
+                    } else {
+                        if (OPT == 5 && jb.kind == kJobRow) acc = xi1 + acc;  // algorithms.cpp:636
+                        const float one[1] = {acc};
+                        float4 piece[1];
+                        uint32_t fd;
+                        const bool mine = gather16<1>(one, lane, piece, fd);  // quads -> 16-byte written-through stores
+                        float *out = jb.kind == kJobRow ? a.Xn + (size_t)jb.row * D : a.partials + (size_t)jb.dst * D;
+                        if constexpr (MB) {
+                            if (jb.kind == kJobRow) {
+                                if (mine) {
+                                    *reinterpret_cast<float4 *>(out + d) = piece[0];
+#ifdef F2V_TEST_HOOKS
+                                    if (jb.row != a.test_withhold_row)
+#endif
+                                    mailbox_store4(a.mailbox + ((size_t)(jb.row - a.chain_lo) * D + d), piece[0], a.seq);
+                                }
+                            } else if (mine) {
+                                store16_agent(out + d, piece[0]);
+                            }
+                        } else if (mine) {
+                            store16_agent(out + d, piece[0]);
+                        }
+#ifdef F2V_TEST_HOOKS
+                        if (!(a.test_nowait & 2u))
+#endif
+                        __builtin_amdgcn_s_waitcnt(0);  // this wavefront's written-through bytes have been acknowledged ...
+                    }
+                }
+                jc += 1u;
+                lds_barrier();  // ... by every wavefront that stored, before one lane announces them
+                if (threadIdx.x == 0u && (jb.kind == kJobPart || (!MB && jb.kind == kJobRow))) {
+                    if (jb.kind == kJobRow) {
+#ifdef F2V_TEST_HOOKS
+                        if (jb.row != a.test_withhold_row)  // fault injection: this row is never announced
+#endif
+                        __hip_atomic_store(a.rowflag + jb.row, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+#ifdef F2V_TEST_HOOKS
+                        if (a.stamps) atomicMax(a.stamps + 4 * (size_t)jb.row + 1, wall_clock64());
+                        if (jb.dst != a.test_withhold_slot)  // fault injection: this sum is never announced
+#endif
+                        __hip_atomic_store(a.ready + jb.dst, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+#ifdef F2V_TEST_HOOKS
+                if (jb.kind == kJobRow && a.stamps && threadIdx.x == 0u) a.stamps[4 * (size_t)jb.row + 2] = wall_clock64();
+#endif
+                continue;
+            }
             if (team < len) {
-                const WJob jb = jobs[jc + team];
+                const WJob jb = job_at(jc + team);
                 if (jb.kind == kJobImport) {
                     // a helper's group sum: wait for its flag (bounded), then agent-scope loads into the LDS slot
                     const unsigned long long t0 = wall_clock64();
@@ -1257,29 +1523,52 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (OPT == 5 ? 4 : 3) : 1) 
                         for (uint32_t c = tl; 4u * c < D; c += 32u) slots[jb.dst][c] = load16_agent(src + 4u * c);
                     }
                 } else {
+                    // slots [first, first + n) added in order, 8 LDS reads in flight
+                    auto add_slots = [&](uint32_t first, uint32_t n, uint32_t c) -> float4 {
+                        float4 acc = slots[first][c];
+                        for (uint32_t k = 1; k < n; k += 8u) {
+                            float4 p[8];
+#pragma unroll
+                            for (uint32_t u = 0; u < 8u; ++u) p[u] = slots[first + (k + u < n ? k + u : n - 1u)][c];
+#pragma unroll
+                            for (uint32_t u = 0; u < 8u; ++u) {
+                                if (k + u < n) { acc.x = acc.x + p[u].x; acc.y = acc.y + p[u].y; acc.z = acc.z + p[u].z; acc.w = acc.w + p[u].w; }
+                            }
+                        }
+                        return acc;
+                    };
                     for (uint32_t c = tl; 4u * c < D; c += 32u) {
                         float4 xi4 = make_float4(0.f, 0.f, 0.f, 0.f);
                         if (OPT == 5 && jb.kind == kJobRow) xi4 = *reinterpret_cast<const float4 *>(a.X + (size_t)jb.row * D + 4u * c);
-                        float4 acc = slots[jb.src][c];
-                        for (uint32_t k = 1; k < jb.n; k += 8u) {  // 8 LDS reads in flight, added in slot order
-                            float4 p[8];
-#pragma unroll
-                            for (uint32_t u = 0; u < 8u; ++u) p[u] = slots[jb.src + (k + u < jb.n ? k + u : jb.n - 1u)][c];
-#pragma unroll
-                            for (uint32_t u = 0; u < 8u; ++u) {
-                                if (k + u < jb.n) { acc.x = acc.x + p[u].x; acc.y = acc.y + p[u].y; acc.z = acc.z + p[u].z; acc.w = acc.w + p[u].w; }
-                            }
-                        }
+#ifdef F2V_TEST_HOOKS
+                        const bool skip_sums = (a.test_nowait & 8u) != 0u;
+#else
+                        constexpr bool skip_sums = false;
+#endif
+                        if (jb.n2 != 0u && !skip_sums) slots[jb.dst2][c] = add_slots(jb.src2, jb.n2, c);  // (read back by this very lane below)
+                        float4 acc = add_slots(jb.src, skip_sums ? 1u : jb.n, c);
                         if (jb.kind == kJobLds) {
                             slots[jb.dst][c] = acc;
                         } else if (jb.kind == kJobPart) {
                             store16_agent(a.partials + (size_t)jb.dst * D + 4u * c, acc);
                         } else {
                             if constexpr (OPT == 5) acc = make_float4(xi4.x + acc.x, xi4.y + acc.y, xi4.z + acc.z, xi4.w + acc.w);  // algorithms.cpp:636
-                            store16_agent(a.Xn + (size_t)jb.row * D + 4u * c, acc);
+                            if constexpr (MB) {
+                                // the new row: for later launches in the second matrix, for later minibatches of this launch as tagged granules
+                                *reinterpret_cast<float4 *>(a.Xn + (size_t)jb.row * D + 4u * c) = acc;
+#ifdef F2V_TEST_HOOKS
+                                if (jb.row != a.test_withhold_row)  // fault injection: this row never arrives
+#endif
+                                mailbox_store4(a.mailbox + ((size_t)(jb.row - a.chain_lo) * D + 4u * c), acc, a.seq);
+                            } else {
+                                store16_agent(a.Xn + (size_t)jb.row * D + 4u * c, acc);
+                            }
                         }
                     }
-                    if (jb.kind != kJobLds) {
+                    if (jb.kind == kJobPart || (!MB && jb.kind == kJobRow)) {
+#ifdef F2V_TEST_HOOKS
+                        if (!(a.test_nowait & 2u))
+#endif
                         __builtin_amdgcn_s_waitcnt(0);  // the written-through bytes have been acknowledged before they are announced
                         if (tl == 0u) {
                             if (jb.kind == kJobRow) {
@@ -1287,9 +1576,6 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (OPT == 5 ? 4 : 3) : 1) 
                                 if (jb.row != a.test_withhold_row)  // fault injection: this row is never announced
 #endif
                                 __hip_atomic_store(a.rowflag + jb.row, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef F2V_TEST_HOOKS
-                                if (a.stamps) a.stamps[4 * (size_t)jb.row + 2] = wall_clock64();
-#endif
                             } else {
 #ifdef F2V_TEST_HOOKS
                                 if (a.stamps) atomicMax(a.stamps + 4 * (size_t)jb.row + 1, wall_clock64());
@@ -1299,14 +1585,17 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (OPT == 5 ? 4 : 3) : 1) 
                             }
                         }
                     }
+#ifdef F2V_TEST_HOOKS
+                    if (jb.kind == kJobRow && a.stamps && tl == 0u) a.stamps[4 * (size_t)jb.row + 2] = wall_clock64();
+#endif
                 }
             }
             jc += len;
-            __syncthreads();  // the pass's sums are in LDS (or announced); its source slots may be reused
+            lds_barrier();  // the pass's sums are in LDS (or on their way to memory); its source slots may be reused
         }
     };
 
-    if (n_jobs && jobs[0].phase == kJobBefore) {
+    if (n_jobs && job_at(0).phase == kJobBefore) {
         run_jobs(kJobBefore);
         if (wg_bad) return;
     }
@@ -1354,7 +1643,7 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (OPT == 5 ? 4 : 3) : 1) 
             c0 = (double)(a.lr * degi);
         }
         bool bad = false;
-        qprocess_pre<OPT, LPI, NB, U, FULL>(a, a.nbr_ids + it.nb, cnt, wave_max_of_items<LPI>(cnt), t, D, xi, Y, c0, table, bad, jpre,
+        qprocess_pre<OPT, LPI, NB, U, FULL, MB>(a, a.nbr_ids + it.nb, cnt, wave_max_of_items<LPI>(cnt), t, D, xi, Y, c0, table, bad, jpre,
                                             a.nbr_ids + itn.nb, (itn.flags & kItemIdle) ? 0u : itn.cnt);
         if (lds_samples) {
             if (!idle && last_chunk) {
@@ -1375,13 +1664,25 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (OPT == 5 ? 4 : 3) : 1) 
         if (!idle && !wave_bad) {
             if (direct) {
                 float *out = a.Xn + (size_t)row * D + t * 4;
+                unsigned long long *g = a.mailbox + ((size_t)(row - a.chain_lo) * D + 4u * t);
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
                     if (!FULL && !(4u * LPI * b + 4u * t < D)) continue;
                     const float4 v = OPT == 5 ? make_float4(xi[b][0] + Y[b][0], xi[b][1] + Y[b][1], xi[b][2] + Y[b][2], xi[b][3] + Y[b][3])  // algorithms.cpp:636
                                               : make_float4(Y[b][0], Y[b][1], Y[b][2], Y[b][3]);
-                    store16_agent(out + 4 * LPI * b, v);
+                    if constexpr (MB) {
+                        *reinterpret_cast<float4 *>(out + 4 * LPI * b) = v;
+#ifdef F2V_TEST_HOOKS
+                        if (row != a.test_withhold_row)
+#endif
+                        mailbox_store4(g + 4 * LPI * b, v, a.seq);
+                    } else {
+                        store16_agent(out + 4 * LPI * b, v);
+                    }
                 }
+#ifdef F2V_TEST_HOOKS
+                if (MB && a.stamps && t == 0u) a.stamps[4 * (size_t)row + 2] = wall_clock64();
+#endif
             } else {
 #pragma unroll
                 for (int b = 0; b < NB; ++b) slots[it.flags & kItemPieceSlot][LPI * b + t] = make_float4(Y[b][0], Y[b][1], Y[b][2], Y[b][3]);
@@ -1390,7 +1691,7 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (OPT == 5 ? 4 : 3) : 1) 
 #endif
             }
         }
-        if (__builtin_amdgcn_ballot_w64(!idle && direct) != 0ull) {
+        if (!MB && __builtin_amdgcn_ballot_w64(!idle && direct) != 0ull) {
             __builtin_amdgcn_s_waitcnt(0);  // the wave's new rows are in memory before they are announced
             if (!idle && direct && !wave_bad && t == 0u) {
 #ifdef F2V_TEST_HOOKS
@@ -1403,8 +1704,8 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (OPT == 5 ? 4 : 3) : 1) 
             }
         }
         if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(it.flags & kItemPhaseEnd)) != 0u) {
-            if (jc < n_jobs && jobs[jc].phase == phase) {
-                __syncthreads();  // the phase's piece sums are in LDS
+            if (jc < n_jobs && job_at(jc).phase == phase) {
+                lds_barrier();  // the phase's piece sums are in LDS
                 if (wg_bad) return;
                 run_jobs(phase);
                 if (wg_bad) return;

@@ -35,7 +35,7 @@ t_stamped = eng.train(option, 1, batch)
 st = np.zeros(4 * n, dtype=np.uint64)
 _lib.check(T.f2v_test_stamps(eng._h, 0, st.ctypes.data_as(C.POINTER(C.c_uint64))), T)
 chunk = eng.get_param("hub_chunk")
-chain_rows = eng.get_param("chain_rows")
+chain_rows = eng.get_param("wide_rows" if eng.get_param("last_train_form") == 2 else "chain_rows")
 fanin = eng.get_param("hub_fanin")
 eng.close()
 st = st.reshape(n, 4)
