@@ -111,6 +111,7 @@ struct f2v_ctx {
     bool recover = true;
     float *d_snap = nullptr;
     uint32_t recoveries = 0;
+    bool unit_degi = false;  // the option being run is 10 (StepArgs::unit_degi): set by every entry point that takes an option
     int last_train_form = 0;  // how the last f2v_train launched: 0 one launch per minibatch, 1 chained, 2 chained in the wide form ("last_train_form")
     bool plan_overflow = false;  // a launch plan needed more than 2^28 partial-sum slots (kItemSlotMask)
     uint32_t *h_kerr = nullptr;  // pinned: the kernel error words as of the last completed epoch-end copy (train_impl)
@@ -1152,6 +1153,7 @@ int launch_step(f2v_ctx *c, int math, uint32_t batch_lo, uint32_t batch_hi, uint
     a.upd_rows = c->upd_hi - c->upd_lo;
     a.ns = ns;
     a.bs_mode = bs_mode ? 1u : 0u;
+    a.unit_degi = c->unit_degi ? 1u : 0u;
     a.lr = lr;
     push = push && c->push.attached && c->push.world > 1;
     if (push) fill_targets(c, a.push, c->cur ^ 1, batch_lo, push_masks);
@@ -1306,6 +1308,7 @@ int launch_chain(f2v_ctx *c, int math, const ChainPlan &plan, const uint32_t *d_
     a.upd_lo = (c->upd_hi == c->upd_lo) ? plan.lo : c->upd_lo;
     a.ns = ns;
     a.bs_mode = bs_mode ? 1u : 0u;
+    a.unit_degi = c->unit_degi ? 1u : 0u;
     a.lr = lr;
     a.fin_items = c->d_hubs + plan.fin_off;
     a.ready = c->d_ready;
@@ -1378,6 +1381,7 @@ int launch_wide(f2v_ctx *c, int math, const WidePlan &plan, const uint32_t *d_id
     a.upd_lo = (c->upd_hi == c->upd_lo) ? plan.lo : c->upd_lo;
     a.ns = ns;
     a.bs_mode = bs_mode ? 1u : 0u;
+    a.unit_degi = c->unit_degi ? 1u : 0u;
     a.lr = lr;
     a.fin_items = c->d_hubs + plan.fin_off;
     a.ready = c->d_ready;
@@ -2131,6 +2135,7 @@ int f2v_minibatch_step(f2v_handle c, int option, uint32_t batch_lo, uint32_t bat
     if (!c) return fail(F2V_EINVAL, "null handle");
     const int math = math_of_option(option);
     if (!math) return fail(F2V_EINVAL, "f2v_minibatch_step: option %d is outside 5..11", option);
+    c->unit_degi = option == 10;
     if (!c->have_x) return fail(F2V_ESTATE, "f2v_minibatch_step: embeddings not initialised");
     if (batch_lo >= batch_hi || batch_hi > c->n) return fail(F2V_EINVAL, "f2v_minibatch_step: bad batch [%u,%u)", batch_lo, batch_hi);
     if (row_lo < batch_lo || row_hi > batch_hi || row_lo > row_hi) return fail(F2V_EINVAL, "f2v_minibatch_step: rows [%u,%u) outside the batch", row_lo, row_hi);
@@ -2170,6 +2175,7 @@ int f2v_minibatch_step_at(f2v_handle c, int option, uint32_t batch_lo, uint32_t 
     if (!c) return fail(F2V_EINVAL, "null handle");
     const int math = math_of_option(option);
     if (!math) return fail(F2V_EINVAL, "f2v_minibatch_step_at: option %d is outside 5..11", option);
+    c->unit_degi = option == 10;
     if (!c->have_x) return fail(F2V_ESTATE, "f2v_minibatch_step_at: embeddings not initialised");
     if (batch_lo >= batch_hi || batch_hi > c->n) return fail(F2V_EINVAL, "f2v_minibatch_step_at: bad batch [%u,%u)", batch_lo, batch_hi);
     if (row_lo < batch_lo || row_hi > batch_hi || row_lo > row_hi) return fail(F2V_EINVAL, "f2v_minibatch_step_at: rows [%u,%u) outside the batch", row_lo, row_hi);
@@ -2330,6 +2336,7 @@ namespace {
 int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t ns, float lr, int bs_mode, double *seconds_out, bool sharded) {
     const int math = math_of_option(option);
     if (!math) return fail(F2V_EINVAL, "f2v_train: option %d is outside 5..11", option);
+    c->unit_degi = option == 10;
     if (!c->have_x) return fail(F2V_ESTATE, "f2v_train: embeddings not initialised (f2v_init_embeddings)");
     if (batch == 0) return fail(F2V_EINVAL, "f2v_train: batch must be positive");
     if (math == 7 && bs_mode) return fail(F2V_EINVAL, "option 7 has no -bs 1 variant");

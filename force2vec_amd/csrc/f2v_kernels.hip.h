@@ -94,6 +94,7 @@ struct StepArgs {
     uint32_t upd_lo, upd_rows;   // rows [upd_lo, upd_lo+upd_rows) are read from Xn
     uint32_t ns;
     uint32_t bs_mode;
+    uint32_t unit_degi;          // option 10: the attraction is NOT divided by deg + 1 (the reference's AVX512 option 10 has `degi = 1.0`, algorithms.cpp:2155, :3793)
     float lr;
     PushTargets push;
     // sub-wave kernel only: the combine trees of this launch's hub rows run in the same grid, behind the step items
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(256) void step_kernel(const StepArgs a) {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) Y[v] = first_chunk ? xi[v] : 0.0f;
         const uint32_t gdeg = a.rowptr[row + 1] - a.rowptr[row];
-        const float degi = (float)(1.0 / (double)(gdeg + 1u));  // algorithms.cpp:854
+        const float degi = a.unit_degi ? 1.0f : (float)(1.0 / (double)(gdeg + 1u));  // algorithms.cpp:854
         c0 = (double)(a.lr * degi);
     }
 
@@ -1121,7 +1122,7 @@ __device__ __forceinline__ void qstep_body(const StepArgs &a, const uint32_t blk
 #pragma unroll
             for (int v = 0; v < 4; ++v) Y[b][v] = first_chunk ? xi[b][v] : 0.0f;
         const uint32_t gdeg = a.rowptr[row + 1] - a.rowptr[row];
-        const float degi = (float)(1.0 / (double)(gdeg + 1u));  // algorithms.cpp:854
+        const float degi = a.unit_degi ? 1.0f : (float)(1.0 / (double)(gdeg + 1u));  // algorithms.cpp:854
         c0 = (double)(a.lr * degi);
     }
 
@@ -1639,7 +1640,7 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (OPT == 5 ? 4 : 3) : 1) 
 #pragma unroll
                 for (int v = 0; v < 4; ++v) Y[b][v] = first_chunk ? xi[b][v] : 0.0f;
             const uint32_t gdeg = a.rowptr[row + 1] - a.rowptr[row];
-            const float degi = (float)(1.0 / (double)(gdeg + 1u));  // algorithms.cpp:854
+            const float degi = a.unit_degi ? 1.0f : (float)(1.0 / (double)(gdeg + 1u));  // algorithms.cpp:854
             c0 = (double)(a.lr * degi);
         }
         bool bad = false;

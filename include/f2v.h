@@ -94,7 +94,8 @@ int f2v_get_param(f2v_handle h, const char *name, int64_t *value_out);
  * their AVX512 twins (sample/algorithms.h:86-102; bodies sample/algorithms.cpp:544-1203,
  * 1230-4051): `iters` epochs of minibatch SGD over all N vertices in batches of `batch`,
  * drawing negative samples (and, for option 7, walks) from the handle's rand() stream in
- * the reference's order.  option: 5|6|7 (8,11 -> 5 ; 9 -> 6 ; 10 -> 7 maths).  bs_mode: the
+ * the reference's order.  option: 5|6|7 (8,11 -> 5 ; 9 -> 6 with its own negative-sample range ; 10 -> 7 without the division of
+ * the attraction by deg + 1, as AlgoForce2VecNSRWEFF_SREAL_D128/D64_AVXZ have it: `degi = 1.0`, sample/algorithms.cpp:2155, :3793).  bs_mode: the
  * CLI's "-bs" (1 = ns*batch samples per minibatch, row i uses samples [i, i+ns)).
  * seconds_out (may be NULL) receives the device time of the epoch loop alone (HIP events);
  * the embeddings stay in HBM (fetch with f2v_get_embeddings). */

@@ -455,8 +455,10 @@ int orc_minibatch(int option, int bs_mode, const uint32_t *rowptr, const uint32_
             row_tdist(X, D, n, i, colids + rowptr[i], gdeg, S, ns, lr, order, chunk, out);
         else if (option == 6)
             row_sigmoid(X, D, n, i, colids + rowptr[i], gdeg, gdeg, S, ns, lr, table, order, chunk, out);
-        else if (option == 7)
-            row_sigmoid(X, D, n, i, walks + (size_t)i * ORC_WALKLENGTH, ORC_WALKLENGTH, gdeg, S, ns, lr,
+        else if (option == 7 || option == 10)
+            /* option 10 (AlgoForce2VecNSRWEFF_SREAL_D128/D64_AVXZ) never divides by the degree: `degi = 1.0` is all it has
+             * (algorithms.cpp:2155, :2345, :3793, :3983) where option 7 sets 1/(deg+1) (:1159) -- a "degree" of 0 here */
+            row_sigmoid(X, D, n, i, walks + (size_t)i * ORC_WALKLENGTH, ORC_WALKLENGTH, option == 10 ? 0u : gdeg, S, ns, lr,
                         table, order, 0 /* the 5 walk samples are never split */, out);
         else { free(snap); free(newrows); free((void *)S); return -2; }
     }
@@ -504,7 +506,8 @@ int orc_train(int option, int bs_mode, const uint32_t *rowptr, const uint32_t *c
               uint32_t ns, float lr, int order, uint32_t chunk, int do_init) {
     if (n < 2 || batch == 0) return -1;
     /* The AVX512 twins (Test/Force2Vec.cpp:152-183) run the maths of options 5/6/7; what differs in their sources besides the
-     * arithmetic details (rcp14, FMA, 4 partial dot sums) is option 9's negative-sample range, kept here as `cli_option`. */
+     * arithmetic details (rcp14, FMA, 4 partial dot sums) is option 9's negative-sample range and option 10's missing degree
+     * normalisation (orc_minibatch), kept here as `cli_option`. */
     const int cli_option = option;
     if (option == 8 || option == 11) option = 5;
     else if (option == 9) option = 6;
@@ -531,7 +534,7 @@ int orc_train(int option, int bs_mode, const uint32_t *rowptr, const uint32_t *c
              * which reaches vertex N-1 when the batch size divides N -- the tail minibatch from [0, N-1) (:1939-1941) */
             if (cli_option == 9 && b < n / batch) maxv = (b + 1) * batch;
             for (uint32_t s = 0; s < ndraw; s++) ids[s] = rand_index(g, maxv, 0);
-            rc = orc_minibatch(option, bs_mode, rowptr, colids, n, D, X, lo, hi, lo, hi, ids, ns, lr,
+            rc = orc_minibatch(cli_option == 10 ? 10 : option, bs_mode, rowptr, colids, n, D, X, lo, hi, lo, hi, ids, ns, lr,
                                walks, order, chunk);
         }
     }
@@ -555,8 +558,8 @@ int orc_row(int option, const uint32_t *rowptr, const uint32_t *colids, uint32_t
         row_tdist(X, D, n, i, colids + rowptr[i], gdeg, S, ns, lr, order, chunk, out);
     else if (option == 6)
         row_sigmoid(X, D, n, i, colids + rowptr[i], gdeg, gdeg, S, ns, lr, table, order, chunk, out);
-    else if (option == 7)
-        row_sigmoid(X, D, n, i, walks + (size_t)i * ORC_WALKLENGTH, ORC_WALKLENGTH, gdeg, S, ns, lr, table,
+    else if (option == 7 || option == 10)
+        row_sigmoid(X, D, n, i, walks + (size_t)i * ORC_WALKLENGTH, ORC_WALKLENGTH, option == 10 ? 0u : gdeg, S, ns, lr, table,
                     order, 0, out);
     else
         rc = -2;

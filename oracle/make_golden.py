@@ -76,6 +76,11 @@ AVX_CASES = [
     ("karate.mtx", 9, 10, 17, 128), ("karate.mtx", 9, 10, 16, 128), ("karate.mtx", 10, 5, 17, 128), ("karate.mtx", 10, 5, 16, 128),
     ("cora.mtx", 8, 1, 677, 128), ("cora.mtx", 8, 10, 677, 128), ("cora.mtx", 11, 10, 677, 128), ("cora.mtx", 8, 100, 677, 128),
     ("cora.mtx", 9, 10, 677, 128), ("cora.mtx", 9, 10, 256, 128), ("cora.mtx", 10, 5, 677, 128), ("cora.mtx", 10, 5, 256, 128),
+    # the D = 64 twins (Test/Force2Vec.cpp:157-176 -> NSRWLB_SREAL_D64 algorithms.cpp:2866-3240, NSRWEFF_SREAL_D64 :3690-4050,
+    # NSLB_SREAL_D64 :3244-3686); option 8 has no D = 64 kernel (it runs the D = 128 one whatever -dim says)
+    ("karate.mtx", 11, 10, 17, 64), ("karate.mtx", 9, 10, 17, 64), ("karate.mtx", 9, 10, 16, 64), ("karate.mtx", 10, 5, 17, 64), ("karate.mtx", 10, 5, 16, 64),
+    ("cora.mtx", 11, 10, 677, 64), ("cora.mtx", 11, 100, 677, 64), ("cora.mtx", 9, 10, 677, 64), ("cora.mtx", 9, 10, 256, 64),
+    ("cora.mtx", 10, 5, 677, 64), ("cora.mtx", 10, 5, 256, 64),
 ]
 
 

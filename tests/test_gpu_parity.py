@@ -652,7 +652,7 @@ def avx512_tolerance(case):
     ~5e-6 from the scalar maths after 1-10 epochs and 1.6e-5 after 100 (measured with the oracle, tests/test_oracle_golden.py);
     options 9/10 have no reciprocal in them: 1e-6, print resolution included."""
     if case["option"] in (8, 11):
-        return 2e-5 if case["iters"] <= 10 else 5e-5
+        return 2e-5 if case["iters"] <= 10 else 5e-5 if case["dim"] == 128 else 2e-4  # (D = 64 rows drift apart sooner: 8.5e-5 after 100 epochs)
     return 5e-6
 
 
@@ -686,8 +686,21 @@ def test_options_8_11_run_option_5_maths_and_10_option_7(F):
         a._run(opt, 0, 3, 16, 5, 0.02, write=False)
         res[opt] = a.nCoordinates
         a.engine.close()
-    assert np.array_equal(res[5], res[8]) and np.array_equal(res[5], res[11]) and np.array_equal(res[7], res[10])
+    assert np.array_equal(res[5], res[8]) and np.array_equal(res[5], res[11])
+    # option 10 = option 7 WITHOUT the division by deg + 1 (`degi = 1.0`, algorithms.cpp:2155): the same bits only while every dot
+    # product saturates the sigmoid (attraction exactly zero either way), as at D = 128 from U[0,1) for these three epochs ...
+    assert np.array_equal(res[7], res[10])
     assert not np.array_equal(res[6], res[9])  # option 9 draws its negative samples from [0, (b+1)*BATCH) in full minibatches
+    # ... and different ones at D = 16, where it does not
+    small = {}
+    for opt in (7, 10):
+        a = F.algorithms((rowptr, colids), dim=16)
+        a.srand(1)
+        a._run(opt, 0, 5, 16, 5, 0.02, write=False)
+        small[opt] = a.nCoordinates
+        a.engine.close()
+        assert np.array_equal(small[opt], O.train(opt, rowptr, colids, 16, 5, 16, order=O.ORDER_TREE, chunk=0))
+    assert not np.array_equal(small[7], small[10])
 
 
 def test_option_11_f1_is_on_the_good_side_of_the_reference(F, manifest):
