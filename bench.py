@@ -127,7 +127,7 @@ def cpu_baseline(args):
             src, dst = edges_from_csr(rowptr, colids)
             write_mtx_fast(mtx, n, src, dst)
             del src, dst
-            cands = sorted({c for c in (32, 64, 128) if c <= cores} or {cores})
+            cands = sorted({c for c in (32, 48, 64, 128) if c <= cores} or {cores})  # (48: the thread count the north star quotes)
             t0 = run(mtx, 0, 1)  # the in-timer initialisation is serial (N*D rand() calls): measured once
             best, best_rate = cands[0], 0.0
             for th in cands:
@@ -181,16 +181,19 @@ def verify_rows(F, eng, rowptr, colids, args, n_rows=32):
     return int(len(rows))
 
 
-def kernel_name(args, pushing):
-    """The step kernel a run of this shape launches (force2vec_amd/csrc/f2v_engine.hip launch_step)."""
+def kernel_name(args, pushing, form):
+    """The step kernel the last f2v_train of this shape launched: `form` is the engine's own answer ("last_train_form": 0 one
+    launch per minibatch, 1 chained, 2 chained in the wide form) -- the launch rules live in f2v_engine.hip, not here."""
     if args.dim % 4 or args.dim > 256:
         return "f2v::step_kernel"
     w = 16
     while w < args.dim:
         w <<= 1
     opt, lpi, nb, u, full = 5 if args.option in (5, 8, 11) else 6, min(16, w // 4), max(1, w // 64), 4 if w >= 128 else 8, "true" if w == args.dim else "false"
-    if not pushing and args.batch <= 4096 and args.option not in (7, 10) and args.dim % 32 == 0 and (1 << args.scale) > args.batch:
-        return "f2v::qstep_chain_kernel<%d, %d, %d, %d, %s>" % (opt, lpi, nb, u, full)  # chained minibatches ("chain_max_batch")
+    if form == 2 and not pushing:
+        return "f2v::qwide_chain_kernel<%d, %d, %d, %d, %s, false>" % (opt, lpi, nb, u, full)
+    if form == 1 and not pushing:
+        return "f2v::qstep_chain_kernel<%d, %d, %d, %d, %s>" % (opt, lpi, nb, u, full)
     return "f2v::qstep_kernel<%d, %d, %d, %d, %s, %s>" % (opt, lpi, nb, u, "true" if pushing else "false", full)
 
 
@@ -267,6 +270,12 @@ def main():
     ap.add_argument("--config5-batch", type=int, default=1048576)
     ap.add_argument("--config4", type=int, default=1, help="also measure BASELINE configs[3] (com-Orkut-sized graph, option 6) and report it under 'extra' (0 = skip)")
     ap.add_argument("--config4-batch", type=int, default=262144)
+    ap.add_argument("--config4-mtx", type=str, default=os.environ.get("F2V_ORKUT_MTX", ""),
+                    help="the real com-orkut.ungraph as a MatrixMarket file (or its .f2vcsr cache), where it has been supplied on this box "
+                         "(also: environment variable F2V_ORKUT_MTX); otherwise a synthetic graph of com-Orkut's size stands in and the line says so")
+    ap.add_argument("--cora", type=int, default=1, help="N=1: also time BASELINE configs[0] and [1] (cora, option 5, batch 256, 1200 epochs at D = 16 / 128) and "
+                                                        "the reference's single-threaded option 5 beside config 0 (reported under 'extra'; 0 = skip)")
+    ap.add_argument("--sustained-s", type=float, default=5.0, help="N=1: the headline workload for this many seconds in ONE f2v_train call, with the rate second by second (0 = skip)")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON result: whatever libraries print there meanwhile (gloo announces its
@@ -553,6 +562,7 @@ def main():
     note(rank, "engine ready, embeddings initialised")
     dt, st, verified = measure(sess, args.steps, args.warmup, args.batch, tune=True)
     main_settle = state["settle_epochs"]
+    main_form = eng.get_param("last_train_form")
     note(rank, "timed region done: %.3f ms per epoch" % (dt / args.steps * 1e3))
     # rForce2Vec attracts along 5 walk samples per vertex, not along the CSR's nonzeros
     units = 5 * n if args.option in (7, 10) else nnz
@@ -589,7 +599,7 @@ def main():
         t_launch = (st["device_seconds"] if st["device_seconds"] else dt) / launches
         comp = st["compulsory_bytes"] / launches
         alg = st["algorithmic_bytes"] / launches
-        kname = kernel_name(args, use_dist and world > 1 and state["exchange"] == "push" and eng.get_param("push_fused"))
+        kname = kernel_name(args, use_dist and world > 1 and state["exchange"] == "push" and eng.get_param("push_fused"), main_form)
         ach = comp / t_launch * 1e-9
         roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                 "kernel": kname, "compulsory_bytes": comp, "compulsory_bytes_per_launch": comp, "avg_launch_us": t_launch * 1e6, "launches": st["step_launches"],
@@ -645,10 +655,102 @@ def main():
             extra["replicas_bit_identical_to_1gpu_run"] = ok
             if not ok:
                 failed.append("extra batches: replica differs from the single-GPU run")
+    if rank == 0 and not use_dist and args.sustained_s > 0:
+        # the headline workload for seconds, in ONE f2v_train call (no host synchronisation inside), with the rate second by
+        # second from HIP events every few epochs ("epoch_marks"): power capping or a clock ramp would show as a drifting rate
+        per_epoch = (st["device_seconds"] if st and st.get("device_seconds") else dt) / args.steps
+        iters = max(8, int(1.05 * args.sustained_s / per_epoch) + 1)
+        every = max(1, iters // 400)
+        eng.set_param("epoch_marks", every)
+        t0 = time.perf_counter()
+        eng.train(args.option, iters, args.batch, 5, 0.02, 0)
+        wall = time.perf_counter() - t0
+        marks = eng.train_marks()
+        eng.set_param("epoch_marks", 0)
+        sess.schedule.append((iters, args.batch, eng.get_param("hub_chunk")))
+        dev = eng.stats()["device_seconds"]
+        rates = []
+        if len(marks) >= 2:
+            sec, last_t, last_k = 1.0, 0.0, 0
+            for k, tm in enumerate(marks):
+                if tm >= sec or k == len(marks) - 1:
+                    rates.append(units * (k + 1 - last_k) * every / max(tm - last_t, 1e-9))
+                    last_t, last_k, sec = tm, k + 1, sec + 1.0
+        extra["sustained"] = {"seconds_device": dev, "seconds_wall": wall, "epochs": iters, "edges_per_s": units * iters / dev,
+                              "per_second_edges_per_s_min": min(rates) if rates else None, "per_second_edges_per_s_max": max(rates) if rates else None,
+                              "per_second_edges_per_s": rates}
+        note(rank, "sustained: %d epochs in %.2f s of device time, %.2f G edges/s" % (iters, dev, units * iters / dev * 1e-9))
     sess.close()
     del sess, eng
+    if rank == 0 and not use_dist and args.cora:
+        # BASELINE configs[0] / [1]: the reference's own bundled graph (tests/golden/cora.mtx is that file), option 5, batch 256,
+        # 1200 epochs, D = 16 and 128: device seconds of the epoch loop; first a 10-epoch run compared with the reference's
+        # committed output (tests/golden, 3e-5) and, bit for bit, with the CPU oracle in the kernels' summation order
+        import gzip
+        from oracle import oracle as O
+        gold = os.path.join(ROOT, "tests", "golden")
+        crp, cci = F.read_mtx(os.path.join(gold, "cora.mtx"))
+        for key, dim in (("config0_cora_D16", 16), ("config1_cora_D128", 128)):
+            ce = F.Engine(crp, cci, dim, device=local_rank)
+            ce.srand(1)
+            ce.init_embeddings(F._lib.INIT_SYMMETRIC)
+            ce.train(5, 10, 256, 5, 0.02, 0)
+            got = ce.get_embeddings()
+            want = O.train(5, crp, cci, dim, 10, 256, order=O.ORDER_TREE, chunk=ce.get_param("hub_chunk"))
+            with gzip.open(os.path.join(gold, "cora_opt5_it10_B256_D%d_bs0.embd.gz" % dim), "rb") as f:
+                tmp = tempfile.NamedTemporaryFile(suffix=".embd", delete=False)
+                tmp.write(f.read())
+                tmp.close()
+                ref = O.read_embd(tmp.name)
+                os.unlink(tmp.name)
+            err = float(np.abs(got - ref).max())
+            if not np.array_equal(got, want) or not err < 3e-5:
+                failed.append("%s: 10 epochs differ from the oracle (bit-identical: %s) or from the reference's committed output by %g" % (key, np.array_equal(got, want), err))
+            best = None
+            for _ in range(3):
+                ce.srand(1)
+                ce.init_embeddings(F._lib.INIT_SYMMETRIC)
+                sec = ce.train(5, 1200, 256, 5, 0.02, 0)
+                best = sec if best is None else min(best, sec)
+            extra[key] = {"workload": "cora.mtx (n=%d, nnz=%d), option 5, D=%d, batch 256, 1200 epochs" % (len(crp) - 1, len(cci), dim),
+                          "seconds_device": best, "edges_per_s": len(cci) * 1200 / best, "launch_form": {0: "one launch per minibatch", 1: "chained", 2: "chained, wide form"}[ce.get_param("last_train_form")],
+                          "epochs10_max_abs_vs_reference_output": err, "epochs10_bit_identical_to_oracle": bool(np.array_equal(got, want))}
+            ce.close()
+        try:  # config 0 as BASELINE words it: the reference CPU path, single thread (oracle/_ref option 5 -threads 1; T(1200) - T(0) strips its in-timer init)
+            if O.ref_binary(False) is not None:
+                with tempfile.TemporaryDirectory() as td:
+                    def ref_seconds(iters):
+                        exe = O.ref_binary(False)
+                        cmd = [exe, "-input", os.path.join(gold, "cora.mtx"), "-output", "/nonexistent_dir_so_no_embd_is_written/", "-iter", str(iters), "-batch", "256",
+                               "-dim", "16", "-nsamples", "5", "-lr", "0.02", "-option", "5", "-threads", "1"]
+                        out = subprocess.run(cmd, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, check=True).stdout
+                        return float([l for l in out.splitlines() if "Wall time required" in l][0].split(":")[-1].split()[0])
+                    t_ref = ref_seconds(1200) - ref_seconds(0)
+                extra["config0_cora_D16"]["reference_cpu_1_thread_seconds"] = t_ref
+                extra["config0_cora_D16"]["reference_cpu_1_thread_edges_per_s"] = len(cci) * 1200 / t_ref
+        except Exception as ex:
+            extra["config0_cora_D16"]["reference_cpu_1_thread_seconds"] = "failed: %r" % (ex,)
     def load_orkut_like():
-        """BASELINE configs[3]'s size (com-Orkut itself is not available offline): cached like the RMAT graphs."""
+        """BASELINE configs[3]: com-Orkut itself where its file has been supplied (--config4-mtx / F2V_ORKUT_MTX: parsed once by
+        libf2v's reader, kept as a binary CSR next to it when the directory is writable, else under /tmp), otherwise a
+        synthetic graph of its size (3 072 441 vertices, 117 185 083 edges), cached like the RMAT graphs."""
+        if args.config4_mtx and os.path.exists(args.config4_mtx):
+            path = args.config4_mtx
+            if path.endswith(".f2vcsr"):
+                return F.graph.read_csr_bin(path)
+            for cache in (path + ".f2vcsr", "/tmp/f2v_orkut_real.f2vcsr"):
+                if os.path.exists(cache) and os.path.getmtime(cache) >= os.path.getmtime(path):
+                    return F.graph.read_csr_bin(cache)
+            t0 = time.time()
+            rp, ci = F.read_mtx(path)
+            log("bench: parsed %s: n=%d nnz=%d in %.1fs" % (path, len(rp) - 1, len(ci), time.time() - t0))
+            for cache in (path + ".f2vcsr", "/tmp/f2v_orkut_real.f2vcsr"):
+                try:
+                    F.graph.write_csr_bin(cache, rp, ci)
+                    break
+                except Exception:
+                    continue
+            return rp, ci
         from force2vec_amd.graph import orkut_like_csr
         cache = "/tmp/f2v_orkut_like_seed1.npz"
         if os.path.exists(cache):
@@ -705,7 +807,10 @@ def main():
             "RMAT scale-%d" % args.config5_scale, lambda: load_graph(args.config5_scale, 16, 1), 11, args.config5_batch)
     if args.config4:
         # BASELINE configs[3]: com-Orkut's size (3.07 M vertices, 117 M edges; synthetic stand-in), option 6 (sigmoid)
-        extra["config4_orkut_sized_option6"] = extra_config("Orkut-sized power-law graph", load_orkut_like, 6, args.config4_batch)
+        real = bool(args.config4_mtx and os.path.exists(args.config4_mtx))
+        extra["config4_orkut_option6" if real else "config4_orkut_sized_option6"] = extra_config(
+            "com-Orkut (%s)" % args.config4_mtx if real else "Orkut-sized synthetic power-law graph (the real com-orkut.ungraph file was not supplied: --config4-mtx / F2V_ORKUT_MTX)",
+            load_orkut_like, 6, args.config4_batch)
     if extra:
         res["extra"] = extra
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

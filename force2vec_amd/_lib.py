@@ -52,6 +52,7 @@ SIGNATURES = {
     "f2v_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "f2v_synchronize": (C.c_int, [C.c_void_p]),
     "f2v_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "f2v_train_marks": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_uint32, u32p]),
     "f2v_push_export": (C.c_int, [C.c_void_p, C.c_void_p]),
     "f2v_push_attach": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "f2v_push_selftest": (C.c_int, [C.c_void_p]),

@@ -112,6 +112,8 @@ struct f2v_ctx {
     float *d_snap = nullptr;
     uint32_t recoveries = 0;
     bool unit_degi = false;  // the option being run is 10 (StepArgs::unit_degi): set by every entry point that takes an option
+    uint32_t mark_every = 0;       // "epoch_marks"
+    std::vector<double> marks;     // f2v_train_marks
     int last_train_form = 0;  // how the last f2v_train launched: 0 one launch per minibatch, 1 chained, 2 chained in the wide form ("last_train_form")
     bool plan_overflow = false;  // a launch plan needed more than 2^28 partial-sum slots (kItemSlotMask)
     uint32_t *h_kerr = nullptr;  // pinned: the kernel error words as of the last completed epoch-end copy (train_impl)
@@ -497,12 +499,18 @@ uint32_t chain_len(const f2v_ctx *c, uint32_t batch, bool wide_form = false) {
     return (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(k, 1));
 }
 
+// the wide form of a chained launch: jobs add at most 32 LDS slots, so the fan-in groups must fit
+bool wide_usable(const f2v_ctx *c) { return c->wide && c->fanin >= 2 && c->fanin <= 32 && c->waves_per_block == 4; }
+
 bool chain_usable(const f2v_ctx *c, int math, uint32_t batch, int bs_mode, bool sharded) {
     const uint32_t nb = (uint32_t)(((uint64_t)c->n + batch - 1) / batch);
     (void)bs_mode;  // -bs 1 chains too: its per-row sample windows are gathered per item, and those gathers wait for rows like any other
     (void)math;     // option 7 chains too: its five walk samples per row are gathered (and waited for) like CSR neighbours
+    // rows narrower than a 128-byte line (D = 16, 8, 4 ...): only in the wide form, whose handed-off rows are read with agent-scope
+    // loads alone, and only where no line holds rows of two minibatches (every reader then treats all of a line's rows alike)
+    const bool lines_ok = c->D % 32u == 0u || (wide_usable(c) && batch <= c->wide_max_batch && chain_len(c, batch, true) >= 2 && ((uint64_t)batch * c->D) % 32u == 0u);
     return c->chain && !sharded && c->merge_fin && c->xcc_round_robin && !c->capturing && !c->use_graph &&
-           subwave_width(c) != 0 && c->D % 32u == 0u && batch <= c->chain_max_batch && nb >= 2 && chain_len(c, batch) >= 2;
+           subwave_width(c) != 0 && lines_ok && batch <= c->chain_max_batch && nb >= 2 && chain_len(c, batch) >= 2;
 }
 
 // The work of minibatches [b0, b0+K) of batch size `batch` as ONE launch: per minibatch its items (rows whose neighbours all
@@ -629,9 +637,6 @@ const ChainPlan &chain_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t ba
     return c->chains.emplace(key, p).first->second;
 }
 
-
-// the wide form of a chained launch: jobs add at most 32 LDS slots, so the fan-in groups must fit
-bool wide_usable(const f2v_ctx *c) { return c->wide && c->fanin >= 2 && c->fanin <= 32 && c->waves_per_block == 4; }
 
 // Minibatches [b0, b0+K) as ONE launch of qwide_chain_kernel: per minibatch the helper workgroups of its multi-group rows,
 // then their finishers, then the workgroups that pack whole low-degree rows and rows of one fan-in group, then the
@@ -1423,6 +1428,7 @@ int launch_wide(f2v_ctx *c, int math, const WidePlan &plan, const uint32_t *d_id
         else { if (full) F2V_W2(OPT, LPI, NB, U, true, false); else F2V_W2(OPT, LPI, NB, U, false, false); }       \
     } while (0)
     switch (width) {
+        case 16: if (o == 5) F2V_W(5, 4, 1, 8); else F2V_W(6, 4, 1, 8); break;
         case 32: if (o == 5) F2V_W(5, 8, 1, 8); else F2V_W(6, 8, 1, 8); break;
         case 64: if (o == 5) F2V_W(5, 16, 1, 8); else F2V_W(6, 16, 1, 8); break;
         case 128: if (o == 5) F2V_W(5, 16, 2, 4); else F2V_W(6, 16, 2, 4); break;
@@ -1990,6 +1996,11 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
         c->wide_mailbox = value != 0;
         return F2V_OK;
     }
+    if (!strcmp(name, "epoch_marks")) {
+        if (value < 0 || value > 0x7FFFFFFF) return fail(F2V_EINVAL, "epoch_marks out of range");
+        c->mark_every = (uint32_t)value;
+        return F2V_OK;
+    }
     if (!strcmp(name, "chain_poll2")) {
         c->wide_poll2 = value != 0;
         return F2V_OK;
@@ -2063,6 +2074,7 @@ int f2v_get_param(f2v_handle c, const char *name, int64_t *out) {
     if (!strcmp(name, "chain_timeout_ms")) { *out = c->chain_timeout_ms; return F2V_OK; }
     if (!strcmp(name, "chain_wide")) { *out = c->wide ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "chain_mailbox")) { *out = c->wide_mailbox ? 1 : 0; return F2V_OK; }
+    if (!strcmp(name, "epoch_marks")) { *out = c->mark_every; return F2V_OK; }
     if (!strcmp(name, "chain_poll2")) { *out = c->wide_poll2 ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "wide_phases")) { *out = c->wide_phases; return F2V_OK; }
     if (!strcmp(name, "wide_max_batch")) { *out = c->wide_max_batch; return F2V_OK; }
@@ -2320,6 +2332,13 @@ int f2v_train(f2v_handle c, int option, uint32_t iters, uint32_t batch, uint32_t
     return rc;
 }
 
+int f2v_train_marks(f2v_handle c, double *seconds_out, uint32_t cap, uint32_t *count_out) {
+    if (!c || (cap && !seconds_out)) return fail(F2V_EINVAL, "f2v_train_marks: null argument");
+    if (count_out) *count_out = (uint32_t)c->marks.size();
+    for (uint32_t k = 0; k < cap && k < c->marks.size(); k++) seconds_out[k] = c->marks[k];
+    return F2V_OK;
+}
+
 int f2v_train_sharded(f2v_handle c, int option, uint32_t iters, uint32_t batch, uint32_t ns, float lr, int bs_mode,
                       double *seconds_out) {
     if (!c) return fail(F2V_EINVAL, "null handle");
@@ -2449,6 +2468,8 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
         ~Events() { for (hipEvent_t e : all) (void)hipEventDestroy(e); }
     } events;
     hipEvent_t ev0, ev1;
+    std::vector<hipEvent_t> mark_ev;  // "epoch_marks"
+    c->marks.clear();
     if ((rc = events.make(&ev0, hipEventDefault)) != F2V_OK || (rc = events.make(&ev1, hipEventDefault)) != F2V_OK) return rc;
     HIPC(hipEventRecord(ev0, c->stream));
 #ifdef F2V_TEST_HOOKS
@@ -2649,6 +2670,12 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
             }
         }
         if (exchanging) c->push.rows_pushed += need_based ? c->push.pushed_per_epoch : (uint64_t)0;
+        if (c->mark_every && (it + 1) % c->mark_every == 0 && mark_ev.size() < 4096) {
+            hipEvent_t e;
+            if ((rc = events.make(&e, hipEventDefault)) != F2V_OK) return rc;
+            HIPC(hipEventRecord(e, c->stream));
+            mark_ev.push_back(e);
+        }
         if (c->merge_fin) {
             const int slot = (int)(it % kErrRing);
             const uint32_t *bad = poll_errors(err_used[slot], slot);  // the slot about to be reused is waited for (4 epochs old)
@@ -2685,6 +2712,11 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
     HIPC(hipEventElapsedTime(&ms, ev0, ev1));
     c->stats.device_seconds = ms * 1e-3;
     if (seconds_out) *seconds_out = ms * 1e-3;
+    for (hipEvent_t e : mark_ev) {
+        float mm = 0.f;
+        HIPC(hipEventElapsedTime(&mm, ev0, e));
+        c->marks.push_back(mm * 1e-3);
+    }
     if ((rc = check_kernel_err(c, sharded ? "f2v_train_sharded" : "f2v_train")) != F2V_OK) return rc;
     if (exchanging) return check_push_err(c, "f2v_train_sharded");
     return F2V_OK;

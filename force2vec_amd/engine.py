@@ -194,6 +194,14 @@ class Engine:
         self._ck(self._L.f2v_stream(self._h, C.byref(s)))
         return s.value
 
+    def train_marks(self):
+        """Device seconds from the start of the last f2v_train's epoch loop to every "epoch_marks"-th epoch's end."""
+        n = C.c_uint32()
+        self._ck(self._L.f2v_train_marks(self._h, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), dtype=np.float64)
+        self._ck(self._L.f2v_train_marks(self._h, out.ctypes.data_as(C.POINTER(C.c_double)), n.value, C.byref(n)))
+        return out[: n.value]
+
     def stats(self):
         s = _lib.Stats()
         self._ck(self._L.f2v_get_stats(self._h, C.byref(s)))

@@ -216,6 +216,11 @@ typedef struct {
     uint64_t compulsory_bytes;
 } f2v_stats;
 int f2v_get_stats(f2v_handle h, f2v_stats *out);
+/* With "epoch_marks" = k > 0 the next f2v_train records a HIP event on its stream after every k-th epoch (at most 4096 of
+ * them); afterwards f2v_train_marks copies the device time from the start of the epoch loop to each mark into `seconds_out`
+ * (up to `cap` values; `count_out` receives how many there are): the rate over a long run second by second, without a host
+ * synchronisation inside the loop. */
+int f2v_train_marks(f2v_handle h, double *seconds_out, uint32_t cap, uint32_t *count_out);
 
 /* ---- host-side I/O of the drop-in boundary (no device needed) ----------------------------
  * f2v_read_mtx replaces SetInputMatricesAsCSR (sample/commonutility.h:44-54 -> ReadASCII

@@ -374,12 +374,15 @@ def _need_round_robin_dispatch(F):
 
 @pytest.mark.parametrize("option,dim,batch,graph,ns", [(5, 128, 256, "rmat", 5), (5, 128, 384, "rmat", 5), (6, 128, 100, "rmat", 5), (5, 32, 64, "rmat", 5),
                                                         (6, 64, 1000, "rmat", 5), (5, 256, 500, "rmat", 5), (6, 96, 37, "cora", 5), (5, 128, 1, "karate", 5),
-                                                        (5, 128, 3000, "rmat", 5), (5, 128, 200, "rmat", 0), (6, 128, 300, "rmat", 11), (5, 64, 128, "rmat", 9)])
+                                                        (5, 128, 3000, "rmat", 5), (5, 128, 200, "rmat", 0), (6, 128, 300, "rmat", 11), (5, 64, 128, "rmat", 9),
+                                                        (5, 16, 64, "rmat", 5), (6, 16, 256, "cora", 5), (5, 48, 64, "rmat", 5), (6, 16, 50, "rmat", 9)])
 def test_chained_minibatches_equal_one_launch_per_minibatch(F, option, dim, batch, graph, ns):
     """ "chain_batches": up to 64 consecutive minibatches in ONE launch, ordered by data dependencies (completion counters
     per minibatch, per-workgroup dependency masks, sample dependencies per epoch) instead of launch boundaries -- bit for
     bit the same embeddings as one launch per minibatch, epoch after epoch, ragged last minibatch included; and equal to
-    the oracle.  ns = 0, and ns > 8 (negative samples gathered per item instead of staged in LDS: they wait for rows too)."""
+    the oracle.  ns = 0, and ns > 8 (negative samples gathered per item instead of staged in LDS: they wait for rows too).
+    Round 3: minibatches of up to 2048 rows run in the WIDE form (the pieces of a row meet in LDS), batch 3000 in the round-2 form;
+    rows narrower than a 128-byte line (D = 16, 48) chain too where no line holds rows of two minibatches (batch * D a multiple of 32)."""
     _need_round_robin_dispatch(F)
     from force2vec_amd.graph import rmat_csr
     if graph == "rmat":
@@ -400,6 +403,7 @@ def test_chained_minibatches_equal_one_launch_per_minibatch(F, option, dim, batc
         eng.train(option, 2, batch, ns)
         launches.append(eng.stats()["step_launches"])
         res.append(eng.get_embeddings())
+        assert eng.get_param("last_train_form") == (0 if not chain else 2 if batch <= 2048 else 1)
         eng.close()
     nb = -(-(len(rowptr) - 1) // batch)
     assert launches[1] == 2 * nb and launches[0] <= 2 * (-(-nb // 2))  # really chained: at least two minibatches per launch
@@ -407,6 +411,46 @@ def test_chained_minibatches_equal_one_launch_per_minibatch(F, option, dim, batc
     if graph != "rmat" or batch >= 256:
         want = O.train(option, rowptr, colids, dim, 5, batch, ns=ns, order=O.ORDER_TREE, chunk=8)
         assert np.array_equal(res[0], want)
+
+
+@pytest.mark.parametrize("option,dim,chunk,fanin,tune", [
+    (5, 128, 4, 32, {}), (5, 128, 2, 32, {"wide_span": 1, "wide_finish": 1}), (6, 128, 4, 4, {"wide_phases": 3}), (5, 64, 8, 2, {"wide_finish": 2, "wide_span": 4}),
+    (6, 32, 3, 32, {"wide_phases": 2, "wide_rows": 4096}), (5, 256, 4, 8, {"wide_finish": 8}), (5, 16, 4, 32, {}), (5, 128, 4, 32, {"wide_order": 2, "chain_poll2": 1})])
+def test_wide_form_equals_the_other_launch_forms(F, option, dim, chunk, fanin, tune):
+    """The three ways f2v_train can launch small minibatches -- one launch each; chained with partial sums through HBM and
+    combine-tree nodes (round 2); chained in the wide form (round 3: a row's pieces meet in LDS, finisher + helper workgroups,
+    tree nodes only above fanin^2 pieces) -- add the same numbers in the same order: identical bits, for every fan-in, chunk
+    and split of a row between finisher and helpers (RMAT scale 14: hubs of thousands of neighbours, i.e. rows of one group,
+    of several, and of more than fanin^2 pieces), and identical to the oracle."""
+    _need_round_robin_dispatch(F)
+    from force2vec_amd.graph import rmat_csr
+    rowptr, colids = rmat_csr(14, 16, seed=4)
+    batch = 128
+    res = {}
+    O.set_fanin(fanin)
+    try:
+        for form in (2, 1, 0):
+            eng = F.Engine(rowptr, colids, dim)
+            eng.set_param("hub_chunk", chunk)
+            eng.set_param("hub_fanin", fanin)
+            eng.set_param("chain_batches", 1 if form else 0)
+            eng.set_param("chain_wide", 1 if form == 2 else 0)
+            if form == 2:
+                for k, v in tune.items():
+                    eng.set_param(k, v)
+            eng.srand(1)
+            eng.init_embeddings(0 if option == 5 else 1)
+            eng.train(option, 2, batch)
+            eng.train(option, 1, batch)
+            if dim % 32 == 0 or form != 1:  # (rows narrower than a line chain only in the wide form)
+                assert eng.get_param("last_train_form") == form
+            res[form] = eng.get_embeddings()
+            eng.close()
+        assert np.array_equal(res[2], res[0]) and np.array_equal(res[1], res[0]) and np.isfinite(res[0]).all()
+        want = O.train(option, rowptr, colids, dim, 3, batch, order=O.ORDER_TREE, chunk=chunk)
+        assert np.array_equal(res[2], want)
+    finally:
+        O.set_fanin(32)
 
 
 def _csr(n, edges):
@@ -1009,7 +1053,7 @@ def test_bench_contract_on_a_small_graph(tmp_path):
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--scale", "15", "--batch", "8192", "--steps", "3", "--warmup", "1",
                         "--no-cpu-baseline", "--extra-batches", "384,2048", "--config5-scale", "16", "--config5-batch", "16384", "--config4", "0",
-                        "--settle-ms", "5"], capture_output=True, text=True, timeout=600)
+                        "--settle-ms", "5", "--sustained-s", "0.2"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout
@@ -1021,4 +1065,12 @@ def test_bench_contract_on_a_small_graph(tmp_path):
     assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and 0.0 < roof["frac"] <= 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
     assert roof["compulsory_bytes_per_launch"] <= roof["algorithmic_bytes_per_launch"] and "qstep" in roof["kernel"]
     assert res["config"]["verified_rows"] >= 24 and "failed" not in res
-    assert set(res["extra"]) == {"batch_384", "batch_2048", "config5_rmat16_option11"} and res["extra"]["config5_rmat16_option11"]["verified_rows"] >= 24
+    assert set(res["extra"]) == {"batch_384", "batch_2048", "config5_rmat16_option11", "sustained", "config0_cora_D16", "config1_cora_D128"}
+    assert res["extra"]["config5_rmat16_option11"]["verified_rows"] >= 24
+    sus = res["extra"]["sustained"]
+    assert sus["seconds_device"] >= 0.15 and sus["epochs"] >= 8 and sus["edges_per_s"] > 0
+    for key in ("config0_cora_D16", "config1_cora_D128"):  # BASELINE configs[0] / [1], with their in-run checks against the reference's output
+        c = res["extra"][key]
+        assert c["epochs10_bit_identical_to_oracle"] and c["epochs10_max_abs_vs_reference_output"] < 3e-5 and 0 < c["seconds_device"] < 5
+        assert c["launch_form"] == "chained, wide form"   # (D = 16 included: 64-byte rows, minibatches end on 128-byte lines)
+    assert "reference_cpu_1_thread_seconds" in res["extra"]["config0_cora_D16"]

@@ -32,12 +32,22 @@ def main():
     prof, out = sys.argv[1], sys.argv[2]
     batch, scale, dim = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
     option = int(sys.argv[6]) if len(sys.argv) > 6 else 5
-    K = "qstep_kernel"
+    # the step kernel of the run: the name the bench line reports (one launch per minibatch, chained, or the wide form) up to its
+    # template list; without a bench line any of the three
+    K = None
+    try:
+        K = json.loads([l for l in open(os.path.join(prof, "pmc_fetch.json")) if l.startswith("{")][-1])["roofline"]["kernel"].split("::")[-1].split("<")[0]
+    except Exception:
+        pass
+    if not K:
+        K = "_kernel"  # (qstep_kernel / qstep_chain_kernel / qwide_chain_kernel are the only kernels of the timed region)
     step = {}
     for name in ("fetch", "write", "l2", "ea_rd", "ea_wr", "sq"):
         c, nd = counters(os.path.join(prof, "pmc_" + name), K)
         step.update(c)
         step["launches_" + name] = nd
+    if "FETCH_SIZE" not in step or "WRITE_SIZE" not in step:
+        sys.exit("parse_pmc: no counters found for a kernel named *%s* under %s (is the kernel name right?)" % (K, prof))
     bench_line = {}
     try:
         bench_line = json.loads([l for l in open(os.path.join(prof, "pmc_fetch.json")) if l.startswith("{")][-1])
