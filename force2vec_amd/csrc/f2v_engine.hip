@@ -152,6 +152,7 @@ struct f2v_ctx {
     uint32_t wide_rows = 262144;     // rows one launch of the wide form covers ("chain_rows" is the HBM form's)
     uint32_t wide_order = 0;    // workgroups of a minibatch: 0 helpers, finishers, packed rows; 1 helpers, packed, finishers; 2 packed, helpers, finishers
     uint32_t wide_phases = 1;   // phases (of 32 piece slots) a workgroup of small rows runs
+    uint32_t wide_rounds = 0;   // rounds per phase of such a workgroup (0: one for minibatches of up to 512 rows, else as many as fill the piece slots)
     uint32_t wide_span = 2;     // fan-in groups per helper workgroup
     uint32_t wide_finish = 4;   // fan-in groups the finisher workgroup keeps for itself (the ones that wait longest)
     uint32_t *d_rowflag = nullptr;  // per row: sequence number of the chained launch that last wrote it
@@ -173,6 +174,7 @@ struct f2v_ctx {
     bool fast_rng = false;        // non-parity mode: device-side init and option-7 walks (counter-based RNG)
     uint64_t fast_seed = 1, fast_epoch = 0;
     int rows_in_flight = 0;  // 0: the kernels' default (4 at D = 128 and 256, 8 below)
+    uint32_t class_split_min = 0;  // "class_split_min" (is_split)
     bool class_cut = true;         // split rows are also cut where their neighbour ids cross into the next eighth of the id range (piece_cuts)
     bool piece_affinity = true;    // hub pieces are placed on the XCD that owns their neighbours' id range (see plan_for)
     bool shared_card = false;      // a peer of the push exchange runs on the same GPU: placement goes back to same-XCD groups
@@ -290,6 +292,18 @@ void piece_cuts(const f2v_ctx *c, uint32_t row, std::vector<uint32_t> &cuts) {
     cuts.push_back(deg);
 }
 
+// Is row i cut into pieces?  More than `chunk` neighbours; or ("class_split_min" = k > 0, with "class_cut") more than k
+// neighbours that lie in more than one of the kIdClasses id ranges: such a row is cut at the class boundaries alone, so that
+// its pieces too run on the XCD whose L2 holds their neighbours' range ("piece_affinity").  Part of the summation order like
+// `chunk` itself (oracle: orc_set_class_split_min).
+bool is_split(const f2v_ctx *c, uint32_t i) {
+    const uint32_t rp = c->rowptr[i], deg = c->rowptr[i + 1] - rp;
+    if (c->chunk == 0) return false;
+    if (deg > c->chunk) return true;
+    if (!c->class_cut || c->class_split_min == 0 || deg <= c->class_split_min) return false;
+    return (uint32_t)(((uint64_t)c->colids[rp] * kIdClasses) / c->n) != (uint32_t)(((uint64_t)c->colids[rp + deg - 1] * kIdClasses) / c->n);
+}
+
 // Compulsory bytes of one minibatch: every DISTINCT embedding row it reads (its own rows and their neighbours) once, every
 // row it writes once, its neighbour ids and work items once -- what would still cross HBM if everything read twice inside
 // the minibatch came from a cache the second time.  (The ns sampled rows, the partial sums of split rows and rowptr are
@@ -357,7 +371,7 @@ const Plan &plan_for(f2v_ctx *c, uint32_t row_lo, uint32_t row_hi, bool walk) {
         }
         const uint32_t rp = c->rowptr[i], deg = c->rowptr[i + 1] - rp;
         p.nnz += deg;
-        if (c->chunk != 0 && deg > c->chunk) {
+        if (is_split(c, i)) {
             const uint32_t cut0 = (uint32_t)cuts.size();
             piece_cuts(c, i, cuts);
             const uint32_t nc = (uint32_t)cuts.size() - cut0 - 1;
@@ -559,7 +573,7 @@ const ChainPlan &chain_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t ba
             }
             const uint32_t rp = c->rowptr[i], deg = c->rowptr[i + 1] - rp;
             nnz += deg;
-            if (c->chunk != 0 && deg > c->chunk) {
+            if (is_split(c, i)) {
                 cutbuf.clear();
                 piece_cuts(c, i, cutbuf);
                 const uint32_t nc = (uint32_t)cutbuf.size() - 1;
@@ -728,7 +742,7 @@ const WidePlan &wide_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t batc
             }
             const uint32_t rp = c->rowptr[i], deg = c->rowptr[i + 1] - rp;
             nnz += deg;
-            if (!(c->chunk != 0 && deg > c->chunk)) {
+            if (!is_split(c, i)) {
                 pieces.push_back(Piece{Item{i, rp, deg, kItemFirst | kItemLast | kItemDirect}, dep_of(rp, rp + deg)});
                 packs.push_back(Pack{(uint32_t)pieces.size() - 1, 1, pieces.back().dep, kJobRow, 0, i});
                 continue;
@@ -847,17 +861,21 @@ const WidePlan &wide_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t batc
             });
             std::vector<char> taken(packs.size(), 0);
             size_t head = 0;
+            // items per phase (a longer one-group unit has a phase to itself): one round where minibatches are small -- they are
+            // latency, a second round of whole rows waits behind the first (cora: -15 %); all piece slots where throughput counts
+            const uint32_t rounds = c->wide_rounds ? c->wide_rounds : (batch <= 512u ? 1u : 64u);
+            const uint32_t cap = (uint32_t)std::min<uint64_t>(pslots, (uint64_t)rounds * ipb);
             while (head < order.size()) {
                 Prog g;
                 std::vector<Piece> ph;
                 std::vector<WJob> js;
                 for (uint32_t f = 0; f < std::max(1u, c->wide_phases); f++) {
                     size_t scanned = 0;
-                    for (size_t x = head; x < order.size() && ph.size() < pslots && scanned < 64; x++) {
+                    for (size_t x = head; x < order.size() && ph.size() < cap && scanned < 64; x++) {
                         if (taken[order[x]]) continue;
                         scanned++;
                         const Pack &pk = packs[order[x]];
-                        if (ph.size() + pk.n > pslots) continue;
+                        if (ph.size() + pk.n > cap && !(ph.empty() && pk.n <= pslots)) continue;
                         taken[order[x]] = 1;
                         if (!(pieces[pk.first].it.flags & kItemDirect))
                             js.push_back(mkjob(ph.size(), pk.n, pk.kind, f, pk.dst, pk.row));
@@ -1909,6 +1927,16 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
         c->use_graph = value != 0;
         return F2V_OK;
     }
+    if (!strcmp(name, "class_split_min")) {
+        if (value < 0 || value > 0x7FFFFFFF) return fail(F2V_EINVAL, "class_split_min out of range");
+        HIPC(hipSetDevice(c->device));
+        int rc = flush_pending(c);
+        if (rc != F2V_OK) return rc;
+        HIPC(hipStreamSynchronize(c->stream));
+        c->class_split_min = (uint32_t)value;
+        drop_plans(c);
+        return F2V_OK;
+    }
     if (!strcmp(name, "class_cut")) {
         HIPC(hipSetDevice(c->device));
         int rc = flush_pending(c);
@@ -2005,8 +2033,9 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
         c->wide_poll2 = value != 0;
         return F2V_OK;
     }
-    if (!strcmp(name, "chain_wide") || !strcmp(name, "wide_phases") || !strcmp(name, "wide_span") || !strcmp(name, "wide_finish") || !strcmp(name, "wide_order")) {
-        if (name[0] == 'w' && strcmp(name, "wide_order") && (value < 1 || value > 64)) return fail(F2V_EINVAL, "%s must be 1..64", name);
+    if (!strcmp(name, "chain_wide") || !strcmp(name, "wide_phases") || !strcmp(name, "wide_span") || !strcmp(name, "wide_finish") || !strcmp(name, "wide_order") || !strcmp(name, "wide_rounds")) {
+        if (name[0] == 'w' && strcmp(name, "wide_order") && strcmp(name, "wide_rounds") && (value < 1 || value > 64)) return fail(F2V_EINVAL, "%s must be 1..64", name);
+        if (!strcmp(name, "wide_rounds") && (value < 0 || value > 64)) return fail(F2V_EINVAL, "wide_rounds must be 0..64");
         if (!strcmp(name, "wide_order") && (value < 0 || value > 2)) return fail(F2V_EINVAL, "wide_order must be 0, 1 or 2");
         HIPC(hipSetDevice(c->device));
         int rc = flush_pending(c);
@@ -2016,6 +2045,7 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
         else if (!strcmp(name, "wide_phases")) c->wide_phases = (uint32_t)value;
         else if (!strcmp(name, "wide_span")) c->wide_span = (uint32_t)value;
         else if (!strcmp(name, "wide_order")) c->wide_order = (uint32_t)value;
+        else if (!strcmp(name, "wide_rounds")) c->wide_rounds = (uint32_t)value;
         else c->wide_finish = (uint32_t)value;
         drop_plans(c);
         return F2V_OK;
@@ -2064,6 +2094,7 @@ int f2v_get_param(f2v_handle c, const char *name, int64_t *out) {
     if (!strcmp(name, "count_compulsory")) { *out = c->count_compulsory ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "piece_affinity")) { *out = c->piece_affinity ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "class_cut")) { *out = c->class_cut ? 1 : 0; return F2V_OK; }
+    if (!strcmp(name, "class_split_min")) { *out = c->class_split_min; return F2V_OK; }
     if (!strcmp(name, "shared_card")) { *out = c->shared_card ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "hub_chunk_auto")) { *out = c->chunk_auto ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "push_timeout_ms")) { *out = c->push.timeout_ms; return F2V_OK; }
@@ -2081,6 +2112,7 @@ int f2v_get_param(f2v_handle c, const char *name, int64_t *out) {
     if (!strcmp(name, "wide_rows")) { *out = c->wide_rows; return F2V_OK; }
     if (!strcmp(name, "wide_span")) { *out = c->wide_span; return F2V_OK; }
     if (!strcmp(name, "wide_order")) { *out = c->wide_order; return F2V_OK; }
+    if (!strcmp(name, "wide_rounds")) { *out = c->wide_rounds; return F2V_OK; }
     if (!strcmp(name, "wide_finish")) { *out = c->wide_finish; return F2V_OK; }
     if (!strcmp(name, "last_train_form")) { *out = c->last_train_form; return F2V_OK; }
     if (!strcmp(name, "recover")) { *out = c->recover ? 1 : 0; return F2V_OK; }

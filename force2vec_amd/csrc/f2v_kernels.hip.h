@@ -1369,27 +1369,39 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (OPT == 5 ? 4 : 3) : 1) 
     if constexpr (OPT != 5) {
         for (uint32_t k = threadIdx.x; k < 2048u; k += 256u) sm_lds[k] = a.sm_table[k];
     }
-    bool smp_bad = false;
+    // The minibatch's negative-sample rows, staged in LDS once per workgroup.  Those that an earlier minibatch of this launch
+    // writes (bit k of `late`) are NOT waited for here: the first round's neighbour gathers go out first, and the wait sits
+    // just in front of the first use of the samples (a sample row of the previous minibatch would otherwise hold the whole
+    // workgroup before it has requested anything).
+    uint32_t late = 0;  // (uniform)
     if (lds_samples) {
+        for (uint32_t sidx = 0; sidx < a.ns; ++sidx)
+            if ((a.sample_ids[sidx] - a.chain_lo) < a.chain_rows) late |= 1u << sidx;
         for (uint32_t k = threadIdx.x; k < a.ns * C4; k += 256u) {
             const uint32_t sidx = k / C4, c4 = k % C4;
+            if ((late >> sidx) & 1u) continue;
+            smp[sidx][c4] = (FULL || 4u * c4 < D) ? reinterpret_cast<const float4 *>(row_src(a, a.sample_ids[sidx], D))[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    auto stage_late_samples = [&]() {  // all threads; -> true: a wait gave up
+        bool bad = false;
+        for (uint32_t k = threadIdx.x; k < a.ns * C4; k += 256u) {
+            const uint32_t sidx = k / C4, c4 = k % C4;
+            if (!((late >> sidx) & 1u)) continue;
             const uint32_t sj = a.sample_ids[sidx];
             if (!(FULL || 4u * c4 < D)) {
                 smp[sidx][c4] = make_float4(0.f, 0.f, 0.f, 0.f);
-            } else if ((sj - a.chain_lo) < a.chain_rows) {  // written inside this launch
-                if constexpr (MB) {  // its tagged granules (c4 as a one-lane group of block 0)
-                    float4 v[1];
-                    smp_bad = mailbox_read<1, 1, true>(a, sj, 4u * c4, D, v) || smp_bad;
-                    smp[sidx][c4] = v[0];
-                } else {
-                    smp_bad = wait_row(a, sj) || smp_bad;
-                    smp[sidx][c4] = load16_agent(row_src(a, sj, D) + 4 * c4);
-                }
+            } else if constexpr (MB) {  // its tagged granules (c4 as a one-lane group of block 0)
+                float4 v[1];
+                bad = mailbox_read<1, 1, true>(a, sj, 4u * c4, D, v) || bad;
+                smp[sidx][c4] = v[0];
             } else {
-                smp[sidx][c4] = reinterpret_cast<const float4 *>(row_src(a, sj, D))[c4];
+                bad = wait_row(a, sj) || bad;
+                smp[sidx][c4] = load16_agent(row_src(a, sj, D) + 4 * c4);
             }
         }
-    }
+        return bad;
+    };
     const float *table = OPT == 5 ? a.sm_table : sm_lds;
 
     const Item *items = a.items + bd.a;
@@ -1400,7 +1412,7 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (OPT == 5 ? 4 : 3) : 1) 
     __shared__ WJob ljobs[kWideJobsLds];
     if (threadIdx.x < n_jobs && threadIdx.x < kWideJobsLds) ljobs[threadIdx.x] = gjobs[threadIdx.x];
     auto job_at = [&](uint32_t k) -> WJob { return k < kWideJobsLds ? ljobs[k] : gjobs[k]; };
-    if (__syncthreads_or(smp_bad ? 1 : 0)) return;  // a sample row that never arrived: nobody stores
+    __syncthreads();
     // the workgroup's last job, when it finishes a row alone in its pass (a finisher's): x_i is requested now, not at the end of the hop
     float xi_pre = 0.f;
     uint32_t xi_pre_for = 0xFFFFFFFFu;
@@ -1646,6 +1658,12 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (OPT == 5 ? 4 : 3) : 1) 
         bool bad = false;
         qprocess_pre<OPT, LPI, NB, U, FULL, MB>(a, a.nbr_ids + it.nb, cnt, wave_max_of_items<LPI>(cnt), t, D, xi, Y, c0, table, bad, jpre,
                                             a.nbr_ids + itn.nb, (itn.flags & kItemIdle) ? 0u : itn.cnt);
+        if (late != 0u) {  // (first round only) the sample rows this launch writes: awaited now, behind the round's gathers
+            if (stage_late_samples()) wg_bad = 1u;
+            late = 0u;
+            lds_barrier();
+            if (wg_bad) return;  // a sample row that never arrived: nobody stores
+        }
         if (lds_samples) {
             if (!idle && last_chunk) {
                 for (uint32_t sidx = 0; sidx < a.ns; ++sidx) {
