@@ -174,7 +174,6 @@ struct f2v_ctx {
     bool fast_rng = false;        // non-parity mode: device-side init and option-7 walks (counter-based RNG)
     uint64_t fast_seed = 1, fast_epoch = 0;
     int rows_in_flight = 0;  // 0: the kernels' default (4 at D = 128 and 256, 8 below)
-    uint32_t class_split_min = 0;  // "class_split_min" (is_split)
     bool class_cut = true;         // split rows are also cut where their neighbour ids cross into the next eighth of the id range (piece_cuts)
     bool piece_affinity = true;    // hub pieces are placed on the XCD that owns their neighbours' id range (see plan_for)
     bool shared_card = false;      // a peer of the push exchange runs on the same GPU: placement goes back to same-XCD groups
@@ -292,17 +291,10 @@ void piece_cuts(const f2v_ctx *c, uint32_t row, std::vector<uint32_t> &cuts) {
     cuts.push_back(deg);
 }
 
-// Is row i cut into pieces?  More than `chunk` neighbours; or ("class_split_min" = k > 0, with "class_cut") more than k
-// neighbours that lie in more than one of the kIdClasses id ranges: such a row is cut at the class boundaries alone, so that
-// its pieces too run on the XCD whose L2 holds their neighbours' range ("piece_affinity").  Part of the summation order like
-// `chunk` itself (oracle: orc_set_class_split_min).
-bool is_split(const f2v_ctx *c, uint32_t i) {
-    const uint32_t rp = c->rowptr[i], deg = c->rowptr[i + 1] - rp;
-    if (c->chunk == 0) return false;
-    if (deg > c->chunk) return true;
-    if (!c->class_cut || c->class_split_min == 0 || deg <= c->class_split_min) return false;
-    return (uint32_t)(((uint64_t)c->colids[rp] * kIdClasses) / c->n) != (uint32_t)(((uint64_t)c->colids[rp + deg - 1] * kIdClasses) / c->n);
-}
+// Is row i cut into pieces?  More than `chunk` neighbours.  (Round 3 tried cutting rows of 17 ... 128 neighbours at the id-class
+// boundaries as well, so that their pieces get "piece_affinity" too: L2 hit rate 0.513 -> 0.537, +8 ... 11 % time for the extra
+// partial sums -- profiles/r03_class_split_min_rejected.txt.)
+bool is_split(const f2v_ctx *c, uint32_t i) { return c->chunk != 0 && c->rowptr[i + 1] - c->rowptr[i] > c->chunk; }
 
 // Compulsory bytes of one minibatch: every DISTINCT embedding row it reads (its own rows and their neighbours) once, every
 // row it writes once, its neighbour ids and work items once -- what would still cross HBM if everything read twice inside
@@ -1927,16 +1919,6 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
         c->use_graph = value != 0;
         return F2V_OK;
     }
-    if (!strcmp(name, "class_split_min")) {
-        if (value < 0 || value > 0x7FFFFFFF) return fail(F2V_EINVAL, "class_split_min out of range");
-        HIPC(hipSetDevice(c->device));
-        int rc = flush_pending(c);
-        if (rc != F2V_OK) return rc;
-        HIPC(hipStreamSynchronize(c->stream));
-        c->class_split_min = (uint32_t)value;
-        drop_plans(c);
-        return F2V_OK;
-    }
     if (!strcmp(name, "class_cut")) {
         HIPC(hipSetDevice(c->device));
         int rc = flush_pending(c);
@@ -2094,7 +2076,6 @@ int f2v_get_param(f2v_handle c, const char *name, int64_t *out) {
     if (!strcmp(name, "count_compulsory")) { *out = c->count_compulsory ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "piece_affinity")) { *out = c->piece_affinity ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "class_cut")) { *out = c->class_cut ? 1 : 0; return F2V_OK; }
-    if (!strcmp(name, "class_split_min")) { *out = c->class_split_min; return F2V_OK; }
     if (!strcmp(name, "shared_card")) { *out = c->shared_card ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "hub_chunk_auto")) { *out = c->chunk_auto ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "push_timeout_ms")) { *out = c->push.timeout_ms; return F2V_OK; }

@@ -281,16 +281,10 @@ void orc_set_fanin(uint32_t fanin) { g_fanin = fanin; }
  * are the offsets of the pieces' first neighbours and, last, deg (cuts has room for deg + 1 entries). */
 static uint32_t g_classes = 8;
 void orc_set_class_cut(uint32_t classes) { g_classes = classes; }
-/* "class_split_min" of the engine (0 = off, the default): a row of more than this many neighbours is ALSO cut where its
- * neighbour ids cross from one class of the id range into the next, although it has no more than `chunk` neighbours. */
-static uint32_t g_class_split_min = 0;
-void orc_set_class_split_min(uint32_t k) { g_class_split_min = k; }
 
 static uint32_t piece_cuts(const uint32_t *nbrs, uint32_t deg, uint32_t chunk, uint32_t n, uint32_t *cuts) {
     uint32_t np = 0;
-    const int class_split = chunk != 0 && g_classes != 0 && n != 0 && g_class_split_min != 0 && deg > g_class_split_min &&
-                            (uint32_t)(((uint64_t)nbrs[0] * g_classes) / n) != (uint32_t)(((uint64_t)nbrs[deg - 1] * g_classes) / n);
-    if (chunk == 0 || (deg <= chunk && !class_split)) {
+    if (chunk == 0 || deg <= chunk) {
         cuts[0] = 0;
         cuts[1] = deg;
         return 1;

@@ -59,7 +59,6 @@ def lib():
                                 C.c_uint32, C.c_int]
         L.orc_row.restype = C.c_int
         L.orc_set_class_cut.argtypes = [C.c_uint32]
-        L.orc_set_class_split_min.argtypes = [C.c_uint32]
         L.orc_row.argtypes = [C.c_int, u32p, u32p, C.c_uint32, C.c_uint32, f32p, C.c_uint32, u32p, C.c_uint32,
                               C.c_float, u32p, C.c_int, C.c_uint32, f32p]
         L.orc_write_embd.restype = C.c_int
@@ -141,11 +140,6 @@ def set_sm_table(table=None):
 def set_fanin(fanin=32):
     """Hub combine fan-in of the chunked order (0 = one sequential pass); the engine's "hub_fanin"."""
     lib().orc_set_fanin(fanin)
-
-
-def set_class_split_min(k=0):
-    """Test hook: the engine's "class_split_min" (rows of more than k neighbours are cut at id-class boundaries too; 0 = off)."""
-    lib().orc_set_class_split_min(k)
 
 
 def set_class_cut(classes=8):
