@@ -191,7 +191,7 @@ def kernel_name(args, pushing, form):
         w <<= 1
     opt, lpi, nb, u, full = 5 if args.option in (5, 8, 11) else 6, min(16, w // 4), max(1, w // 64), 4 if w >= 128 else 8, "true" if w == args.dim else "false"
     if form == 2 and not pushing:
-        return "f2v::qwide_chain_kernel<%d, %d, %d, %d, %s, false>" % (opt, lpi, nb, u, full)
+        return "f2v::qwide_chain_kernel<%d, %d, %d, %d, %s>" % (opt, lpi, nb, u, full)
     if form == 1 and not pushing:
         return "f2v::qstep_chain_kernel<%d, %d, %d, %d, %s>" % (opt, lpi, nb, u, full)
     return "f2v::qstep_kernel<%d, %d, %d, %d, %s, %s>" % (opt, lpi, nb, u, "true" if pushing else "false", full)

@@ -102,7 +102,6 @@ struct f2v_ctx {
     float *d_X[2] = {nullptr, nullptr}, *d_partials = nullptr, *d_table = nullptr;
     uint32_t *d_ready = nullptr, *d_kerr = nullptr;  // combine-tree flags (one per partial slot), kernel error word
     uint32_t launch_seq = 0;
-    bool launch_seq_wrapped = false;
     uint32_t xcc_count = 0;      // XCDs seen by the dispatch probe of f2v_create
     bool xcc_round_robin = false;  // ... and workgroup b ran on the XCD of workgroup b mod 8
     int64_t tree_timeout_ms = 5000;
@@ -146,8 +145,6 @@ struct f2v_ctx {
     WJob *d_jobs = nullptr;
     size_t d_wide_cap = 0, d_wide_valid = 0, d_jobs_cap = 0, d_jobs_valid = 0;
     bool wide = true;
-    bool wide_poll2 = false;     // "chain_poll2": two polls of a row flag in flight
-    bool wide_mailbox = false;  // "chain_mailbox": rows handed on as data-tagged granules instead of flag + agent-scope loads
     uint32_t wide_max_batch = 2048;  // larger chained minibatches are throughput-bound: they keep the HBM form (tools/wide_sweep.py)
     uint32_t wide_rows = 262144;     // rows one launch of the wide form covers ("chain_rows" is the HBM form's)
     uint32_t wide_order = 0;    // workgroups of a minibatch: 0 helpers, finishers, packed rows; 1 helpers, packed, finishers; 2 packed, helpers, finishers
@@ -156,8 +153,6 @@ struct f2v_ctx {
     uint32_t wide_span = 2;     // fan-in groups per helper workgroup
     uint32_t wide_finish = 4;   // fan-in groups the finisher workgroup keeps for itself (the ones that wait longest)
     uint32_t *d_rowflag = nullptr;  // per row: sequence number of the chained launch that last wrote it
-    unsigned long long *d_mailbox = nullptr;  // wide form: the launch's rows as data-tagged granules, chain_rows x D x 8 bytes (StepArgs::mailbox)
-    size_t mailbox_rows = 0;
     bool chain = true;            // "chain_batches"
     uint32_t chain_max_batch = 4096, chain_rows = 65536;  // measured on RMAT-20 (tools/small_batch.py, tools/chain_sweep.py)
     std::vector<Item> h_items;
@@ -1403,23 +1398,13 @@ int launch_wide(f2v_ctx *c, int math, const WidePlan &plan, const uint32_t *d_id
     a.err = c->d_kerr;
     a.timeout_ticks = (unsigned long long)std::min(c->tree_timeout_ms, c->chain_timeout_ms) * 100000ull;
     a.seq = ++c->launch_seq;
-    if (a.seq == 0) { a.seq = ++c->launch_seq; c->launch_seq_wrapped = true; }
+    if (a.seq == 0) a.seq = ++c->launch_seq;
 #ifdef F2V_TEST_HOOKS
     a.test_withhold_slot = c->test_withhold_slot;
     a.test_withhold_row = c->test_withhold_row;
 #endif
     a.rowflag = c->d_rowflag;
     a.chain_lo = plan.lo;
-    // rows as tagged granules ("chain_mailbox"): not with -bs 1 / more than 8 samples, whose sample gathers use the flag protocol
-    const bool mb = c->wide_mailbox && !bs_mode && ns <= 8;
-    a.mailbox = mb ? c->d_mailbox : nullptr;
-    a.poll2 = c->wide_poll2 ? 1u : 0u;
-    if (mb && (size_t)(plan.hi - plan.lo) > c->mailbox_rows) return fail(F2V_ESTATE, "launch_wide: the launch covers more rows than the mailbox holds");
-    if (mb && a.seq == 1u && c->launch_seq_wrapped) {
-        // 2^32 launches later a tag could repeat: start from a clean mailbox (stream-ordered)
-        HIPC(hipMemsetAsync(c->d_mailbox, 0, c->mailbox_rows * c->D * sizeof(unsigned long long), c->stream));
-        c->launch_seq_wrapped = false;
-    }
 #ifdef F2V_TEST_HOOKS
     a.test_nowait = c->test_chain_mode;
     a.stamps = c->d_stamps;
@@ -1431,12 +1416,8 @@ int launch_wide(f2v_ctx *c, int math, const WidePlan &plan, const uint32_t *d_id
     const uint32_t width = subwave_width(c);
     const bool full = width == c->D;
     const int o = (math == 5) ? 5 : 6;
-#define F2V_W2(OPT, LPI, NB, U, FULL, MB) hipLaunchKernelGGL((qwide_chain_kernel<OPT, LPI, NB, U, FULL, MB>), dim3(plan.n_wgs), dim3(256), 0, c->stream, wa)
-#define F2V_W(OPT, LPI, NB, U)                                                                        \
-    do {                                                                                              \
-        if (mb) { if (full) F2V_W2(OPT, LPI, NB, U, true, true); else F2V_W2(OPT, LPI, NB, U, false, true); }      \
-        else { if (full) F2V_W2(OPT, LPI, NB, U, true, false); else F2V_W2(OPT, LPI, NB, U, false, false); }       \
-    } while (0)
+#define F2V_W2(OPT, LPI, NB, U, FULL) hipLaunchKernelGGL((qwide_chain_kernel<OPT, LPI, NB, U, FULL>), dim3(plan.n_wgs), dim3(256), 0, c->stream, wa)
+#define F2V_W(OPT, LPI, NB, U) do { if (full) F2V_W2(OPT, LPI, NB, U, true); else F2V_W2(OPT, LPI, NB, U, false); } while (0)
     switch (width) {
         case 16: if (o == 5) F2V_W(5, 4, 1, 8); else F2V_W(6, 4, 1, 8); break;
         case 32: if (o == 5) F2V_W(5, 8, 1, 8); else F2V_W(6, 8, 1, 8); break;
@@ -1750,7 +1731,7 @@ int f2v_destroy(f2v_handle c) {
     (void)hipSetDevice(c->device);
     (void)push_detach(c);
     void *ptrs[] = {c->d_rowptr, c->d_colids, c->d_walks, c->d_walks_alt, c->d_ids, c->d_X[0], c->d_X[1],
-                    c->d_partials, c->d_table, c->d_items, c->d_hubs, c->d_ready, c->d_kerr, c->d_wg, c->d_rowflag, c->d_snap, c->d_wide, c->d_jobs, c->d_mailbox, c->push.flags, c->push.d_err, c->push.d_masks, c->push.d_patch, c->push.landing_buf};
+                    c->d_partials, c->d_table, c->d_items, c->d_hubs, c->d_ready, c->d_kerr, c->d_wg, c->d_rowflag, c->d_snap, c->d_wide, c->d_jobs, c->push.flags, c->push.d_err, c->push.d_masks, c->push.d_patch, c->push.landing_buf};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 #ifdef F2V_TEST_HOOKS
@@ -2002,17 +1983,9 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
         c->tree_timeout_ms = value;
         return F2V_OK;
     }
-    if (!strcmp(name, "chain_mailbox")) {
-        c->wide_mailbox = value != 0;
-        return F2V_OK;
-    }
     if (!strcmp(name, "epoch_marks")) {
         if (value < 0 || value > 0x7FFFFFFF) return fail(F2V_EINVAL, "epoch_marks out of range");
         c->mark_every = (uint32_t)value;
-        return F2V_OK;
-    }
-    if (!strcmp(name, "chain_poll2")) {
-        c->wide_poll2 = value != 0;
         return F2V_OK;
     }
     if (!strcmp(name, "chain_wide") || !strcmp(name, "wide_phases") || !strcmp(name, "wide_span") || !strcmp(name, "wide_finish") || !strcmp(name, "wide_order") || !strcmp(name, "wide_rounds")) {
@@ -2085,9 +2058,7 @@ int f2v_get_param(f2v_handle c, const char *name, int64_t *out) {
     if (!strcmp(name, "chain_batches")) { *out = c->chain ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "chain_timeout_ms")) { *out = c->chain_timeout_ms; return F2V_OK; }
     if (!strcmp(name, "chain_wide")) { *out = c->wide ? 1 : 0; return F2V_OK; }
-    if (!strcmp(name, "chain_mailbox")) { *out = c->wide_mailbox ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "epoch_marks")) { *out = c->mark_every; return F2V_OK; }
-    if (!strcmp(name, "chain_poll2")) { *out = c->wide_poll2 ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "wide_phases")) { *out = c->wide_phases; return F2V_OK; }
     if (!strcmp(name, "wide_max_batch")) { *out = c->wide_max_batch; return F2V_OK; }
     if (!strcmp(name, "wide_rows")) { *out = c->wide_rows; return F2V_OK; }
@@ -2433,19 +2404,6 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
             }
         }
     };
-    if (wide && c->wide_mailbox) {
-        const size_t rows = std::min<size_t>((size_t)K * batch, c->n);
-        if (rows > c->mailbox_rows) {
-            HIPC(hipStreamSynchronize(c->stream));
-            if (c->d_mailbox) (void)hipFree(c->d_mailbox);
-            c->d_mailbox = nullptr;
-            c->mailbox_rows = 0;
-            HIPC(hipMalloc((void **)&c->d_mailbox, rows * c->D * sizeof(unsigned long long)));
-            HIPC(hipMemsetAsync(c->d_mailbox, 0, rows * c->D * sizeof(unsigned long long), c->stream));  // 0 is no launch's sequence number
-            HIPC(hipStreamSynchronize(c->stream));
-            c->mailbox_rows = rows;
-        }
-    }
     if (chained && !c->d_rowflag) {
         HIPC(hipMalloc((void **)&c->d_rowflag, (size_t)c->n * sizeof(uint32_t)));
         HIPC(hipMemsetAsync(c->d_rowflag, 0, (size_t)c->n * sizeof(uint32_t), c->stream));  // 0 is no launch's sequence number

@@ -415,7 +415,7 @@ def test_chained_minibatches_equal_one_launch_per_minibatch(F, option, dim, batc
 
 @pytest.mark.parametrize("option,dim,chunk,fanin,tune", [
     (5, 128, 4, 32, {}), (5, 128, 2, 32, {"wide_span": 1, "wide_finish": 1}), (6, 128, 4, 4, {"wide_phases": 3}), (5, 64, 8, 2, {"wide_finish": 2, "wide_span": 4}),
-    (6, 32, 3, 32, {"wide_phases": 2, "wide_rows": 4096}), (5, 256, 4, 8, {"wide_finish": 8}), (5, 16, 4, 32, {}), (5, 128, 4, 32, {"wide_order": 2, "chain_poll2": 1})])
+    (6, 32, 3, 32, {"wide_phases": 2, "wide_rows": 4096}), (5, 256, 4, 8, {"wide_finish": 8}), (5, 16, 4, 32, {}), (5, 128, 4, 32, {"wide_order": 2, "wide_rounds": 2})])
 def test_wide_form_equals_the_other_launch_forms(F, option, dim, chunk, fanin, tune):
     """The three ways f2v_train can launch small minibatches -- one launch each; chained with partial sums through HBM and
     combine-tree nodes (round 2); chained in the wide form (round 3: a row's pieces meet in LDS, finisher + helper workgroups,
