@@ -67,6 +67,8 @@ SIGNATURES = {
     "f2v_write_csr_bin": (C.c_int, [C.c_char_p, u32p, u32p, C.c_uint32, C.c_uint64]),
     "f2v_read_csr_bin": (C.c_int, [C.c_char_p, u32p, C.POINTER(C.c_uint64), C.POINTER(u32p), C.POINTER(u32p)]),
     "f2v_write_embd_bin": (C.c_int, [C.c_char_p, f32p, C.c_uint32, C.c_uint32]),
+    "f2v_read_embd": (C.c_int, [C.c_char_p, u32p, u32p, C.POINTER(f32p)]),
+    "f2v_read_embd_bin": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, f32p]),
     "f2v_output_name": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p, C.c_size_t]),
     "f2v_rng_create": (C.c_void_p, [C.c_uint32]),
     "f2v_rng_destroy": (None, [C.c_void_p]),

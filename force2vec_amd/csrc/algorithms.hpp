@@ -63,6 +63,7 @@ class algorithms {
     double gpu_train_seconds = 0.0;  // device time of the epoch loop alone
     bool binary_output = false;      // also write "<name>.bin": raw fp32 N x D (readBinEmbeddings format)
     bool text_output = true;         // the reference's text .embd (19 GB at 16 M x 128: switch off with -notext 1)
+    std::string init_path;           // warm start (-init): a text .embd or, ending in ".bin", a raw fp32 N x D file, instead of randInit
     f2v_stats stats{};
     int rank = 0, world = 1;         // > 1 after join_ranks: one process per GPU, minibatch rows sharded (f2v_train_sharded)
 
@@ -149,11 +150,33 @@ class algorithms {
         check(f2v_get_param(h, name, &v));
         return v;
     }
+    // randInitF / randInit (algorithms.cpp:38-53) -- or the embedding file of a warm start
+    void init(int math) {
+        if (init_path.empty()) {
+            check(f2v_init_embeddings(h, math == 5 ? F2V_INIT_SYMMETRIC : F2V_INIT_UNIT));
+            return;
+        }
+        const std::string ext = ".bin";
+        if (init_path.size() > ext.size() && init_path.compare(init_path.size() - ext.size(), ext.size(), ext) == 0) {
+            std::vector<float> x((size_t)rows * DIM);
+            check(f2v_read_embd_bin(init_path.c_str(), rows, DIM, x.data()));
+            check(f2v_set_embeddings(h, x.data()));
+        } else {
+            uint32_t n = 0, d = 0;
+            float *x = nullptr;
+            check(f2v_read_embd(init_path.c_str(), &n, &d, &x));
+            const bool fits = n == rows && d == DIM;
+            if (fits) check(f2v_set_embeddings(h, x));
+            f2v_free(x);
+            if (!fits) throw std::runtime_error("-init: " + init_path + " holds " + std::to_string(n) + " x " + std::to_string(d) + " values, the run needs " +
+                                                std::to_string(rows) + " x " + std::to_string(DIM));
+        }
+    }
     std::vector<VALUETYPE> run(int option, int bs, INDEXTYPE IT, INDEXTYPE B, INDEXTYPE ns, VALUETYPE lr, const char *msg) {
         // the reference's timer spans randInit + the epoch loop (algorithms.cpp:557-558, 647)
         auto t0 = std::chrono::steady_clock::now();
         const int math = (option == 5 || option == 8 || option == 11) ? 5 : 6;
-        check(f2v_init_embeddings(h, math == 5 ? F2V_INIT_SYMMETRIC : F2V_INIT_UNIT));
+        init(math);
         if (world > 1) {
             check(f2v_train_sharded(h, option, IT, B, ns, lr, bs, &gpu_train_seconds));
         } else {
@@ -168,7 +191,7 @@ class algorithms {
             if (rc == F2V_ESTATE && repeatable && param("merge_finalize") == 0) {
                 std::cerr << "Force2Vec: " << f2v_last_error() << "\nForce2Vec: running again from seed " << last_seed << std::endl;
                 check(f2v_srand(h, last_seed));
-                check(f2v_init_embeddings(h, math == 5 ? F2V_INIT_SYMMETRIC : F2V_INIT_UNIT));
+                init(math);
                 rc = f2v_train(h, option, IT, B, ns, lr, bs, &gpu_train_seconds);
             } else if (rc == F2V_OK && param("recoveries") != before) {
                 std::cerr << "Force2Vec: " << f2v_last_error() << std::endl;

@@ -25,7 +25,7 @@ using namespace f2v_host;
 namespace {
 
 struct Settings {
-    std::string input, output;
+    std::string input, output, init;
     long batch = 384, iter = 1200, threads = (long)std::thread::hardware_concurrency(), dim = 128, nsamples = 5, option = 5, bs = 0;
     long device = 0, seed = 1, cache = 0, binout = 0, fastrng = 0, notext = 0, gpus = 1, samegpu = 0;
     double gamma = 1.0, lr = 0.02;
@@ -84,6 +84,7 @@ int main(int argc, char *argv[]) {
         {"-seed", Kind::Integer, &s.seed, "<int>, srand() seed. (default:1)"},
         {"-cache", Kind::Integer, &s.cache, "<int>, 1 = keep / reuse the binary CSR <input>.f2vcsr."},
         {"-binout", Kind::Integer, &s.binout, "<int>, 1 = also write <output file>.bin, raw fp32 N x D (the scorers' binary embedding format)."},
+        {"-init", Kind::Text, &s.init, "<string>, warm start: a text .embd (or, ending in .bin, raw fp32 N x D) of the run's N and -dim instead of the random initial embedding."},
         {"-notext", Kind::Integer, &s.notext, "<int>, 1 = skip the text .embd (use with -binout 1 for very large graphs)."},
         {"-gpus", Kind::Integer, &s.gpus, "<int>, number of GPUs (1..8): one process per GPU from -device on, minibatch rows sharded, rows exchanged over xGMI. (default:1)"},
         {"-samegpu", Kind::Integer, &s.samegpu, "<int>, 1 = all ranks of a -gpus run on device -device (self-test on a one-GPU machine)."},
@@ -148,6 +149,7 @@ int main(int argc, char *argv[]) {
             algorithms algo(graph, s.input, s.output, (INDEXTYPE)s.dim, (VALUETYPE)s.gamma, (INDEXTYPE)s.batch, (int)s.device + (s.samegpu ? 0 : rank));
             algo.binary_output = s.binout != 0;
             algo.text_output = s.notext == 0;
+            algo.init_path = s.init;
             if (s.fastrng && f2v_set_param(algo.h, "fast_rng", 1) != F2V_OK) throw std::runtime_error(f2v_last_error());
             algo.srand((unsigned)s.seed);
             if (s.gpus > 1) algo.join_ranks(rank, (int)s.gpus, meet);

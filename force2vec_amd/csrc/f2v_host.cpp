@@ -148,7 +148,7 @@ using namespace f2v;
 extern "C" {
 
 const char *f2v_last_error(void) { return g_err; }
-const char *f2v_version(void) { return "f2v-mi355x 0.3 (gfx950)"; }
+const char *f2v_version(void) { return "f2v-mi355x 0.4 (gfx950)"; }
 
 f2v_rng *f2v_rng_create(uint32_t seed) {
     Rand *g = new Rand();
@@ -355,6 +355,49 @@ int f2v_write_embd(const char *path, const float *x, uint32_t n, uint32_t dim) {
     }
     if (fclose(fp) != 0) return fail(F2V_EIO, "f2v_write_embd: close failed for %s", path);
     return F2V_OK;
+}
+
+// The reader of what f2v_write_embd / writeToFile wrote ("<N> <D>" then "<id> v0 ... " per row, ids 1-based, any row order):
+// performancescores/runnodeclassclust.py:57-79 reads the same.  *x_out: malloc'ed N x D floats (f2v_free).
+int f2v_read_embd(const char *path, uint32_t *n_out, uint32_t *dim_out, float **x_out) {
+    if (!path || !n_out || !dim_out || !x_out) return fail(F2V_EINVAL, "f2v_read_embd: null argument");
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return fail(F2V_EIO, "f2v_read_embd: cannot open %s: %s", path, strerror(errno));
+    unsigned long long n = 0, dim = 0;
+    if (fscanf(fp, "%llu %llu", &n, &dim) != 2 || n == 0 || dim == 0 || n > 0xFFFFFFFFull || dim > 512) {
+        fclose(fp);
+        return fail(F2V_EIO, "f2v_read_embd: %s does not start with '<N> <D>'", path);
+    }
+    float *x = static_cast<float *>(malloc((size_t)n * dim * sizeof(float)));
+    if (!x) { fclose(fp); return fail(F2V_ENOMEM, "f2v_read_embd: out of memory"); }
+    std::vector<char> seen((size_t)n, 0);
+    for (unsigned long long r = 0; r < n; r++) {
+        unsigned long long id = 0;
+        bool ok = fscanf(fp, "%llu", &id) == 1 && id >= 1 && id <= n && !seen[id - 1];
+        for (unsigned long long d = 0; ok && d < dim; d++) ok = fscanf(fp, "%f", x + (size_t)(id - 1) * dim + d) == 1;
+        if (!ok) {
+            fclose(fp);
+            free(x);
+            return fail(F2V_EIO, "f2v_read_embd: %s: row %llu of %llu is malformed, out of range or repeated", path, r + 1, n);
+        }
+        seen[id - 1] = 1;
+    }
+    fclose(fp);
+    *n_out = (uint32_t)n;
+    *dim_out = (uint32_t)dim;
+    *x_out = x;
+    return F2V_OK;
+}
+
+// Raw fp32 N x D (f2v_write_embd_bin, the scorers' readBinEmbeddings format): the file must hold exactly n * dim floats.
+int f2v_read_embd_bin(const char *path, uint32_t n, uint32_t dim, float *x_out) {
+    if (!path || !x_out) return fail(F2V_EINVAL, "f2v_read_embd_bin: null argument");
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return fail(F2V_EIO, "f2v_read_embd_bin: cannot open %s: %s", path, strerror(errno));
+    const size_t total = (size_t)n * dim;
+    const bool ok = fread(x_out, sizeof(float), total, fp) == total && fgetc(fp) == EOF;
+    fclose(fp);
+    return ok ? F2V_OK : fail(F2V_EIO, "f2v_read_embd_bin: %s does not hold exactly %u x %u floats", path, n, dim);
 }
 
 static const char kCsrMagic[8] = {'F', '2', 'V', 'C', 'S', 'R', '1', 0};

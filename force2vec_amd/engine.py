@@ -237,6 +237,24 @@ def write_embd_bin(path, X):
     check(_lib.lib().f2v_write_embd_bin(str(path).encode(), _f32(X), X.shape[0], X.shape[1]))
 
 
+def read_embd(path):
+    """Text .embd (writeToFile's format) -> float32 [N, D]."""
+    L = _lib.lib()
+    n, d, x = C.c_uint32(), C.c_uint32(), _lib.f32p()
+    check(L.f2v_read_embd(str(path).encode(), C.byref(n), C.byref(d), C.byref(x)))
+    try:
+        return np.ctypeslib.as_array(x, shape=(n.value, d.value)).copy()
+    finally:
+        L.f2v_free(x)
+
+
+def read_embd_bin(path, n, dim):
+    """Raw fp32 N x D file (write_embd_bin) -> float32 [N, D]."""
+    X = np.empty((n, dim), dtype=np.float32)
+    check(_lib.lib().f2v_read_embd_bin(str(path).encode(), n, dim, _f32(X)))
+    return X
+
+
 def output_name(input_path, outdir, option, bs_mode, batch, dim, iters, ns):
     buf = C.create_string_buffer(4096)
     check(_lib.lib().f2v_output_name(str(input_path).encode(), str(outdir).encode(), option, bs_mode, batch, dim, iters, ns, buf, len(buf)))

@@ -246,6 +246,11 @@ int f2v_read_csr_bin(const char *path, uint32_t *n_out, uint64_t *nnz_out, uint3
 /* Raw fp32 N x D embedding file, the format the reference's scorers read with readBinEmbeddings
  * (performancescores/runnodeclassclust.py:81-100); text .embd of 16 M x 128 values is ~19 GB. */
 int f2v_write_embd_bin(const char *path, const float *x, uint32_t n, uint32_t dim);
+/* The readers of both embedding formats (what performancescores/runnodeclassclust.py:57-100 reads): warm starts
+ * (f2v_set_embeddings; `Force2Vec -init <file>`) and scoring without the text round trip.  f2v_read_embd allocates *x_out (N x D
+ * floats, release with f2v_free); rows may come in any order, ids are 1-based. */
+int f2v_read_embd(const char *path, uint32_t *n_out, uint32_t *dim_out, float **x_out);
+int f2v_read_embd_bin(const char *path, uint32_t n, uint32_t dim, float *x_out);
 
 /* Stand-alone libc rand() stream (glibc TYPE_3), for hosts that pre-draw sample ids. */
 typedef struct f2v_rng f2v_rng;

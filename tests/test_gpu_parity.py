@@ -835,6 +835,37 @@ def test_cli_binary_cache_and_output(F, tmp_path):
     assert np.array_equal(X, want)
 
 
+def test_cli_warm_start_from_an_embedding_file(F, tmp_path):
+    """-init <file> (text .embd or raw .bin): the run starts from that embedding instead of randInit -- with -iter 0 it is written
+    back unchanged, and epochs continue from it exactly as the engine does from f2v_set_embeddings."""
+    exe = os.path.join(ROOT, "bin", "Force2Vec")
+    out = str(tmp_path) + "/"
+    mtx = golden_graph_path("karate.mtx")
+    rowptr, colids = F.read_mtx(mtx)
+    rng = np.random.default_rng(3)
+    X0 = rng.uniform(-1, 1, (len(rowptr) - 1, 64)).astype(np.float32)
+    F.write_embd_bin(out + "start.bin", X0)
+    r = subprocess.run([exe, "-input", mtx, "-output", out, "-iter", "0", "-batch", "16", "-dim", "64", "-option", "5", "-init", out + "start.bin", "-binout", "1"],
+                       cwd=out, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert np.array_equal(np.fromfile(out + "karate.mtxF2VNS16D64IT0NS5.embd.bin", np.float32).reshape(-1, 64), X0)
+    F.write_embd(out + "start.embd", X0)
+    X0t = F.read_embd(out + "start.embd")                                   # (6 printed digits)
+    r = subprocess.run([exe, "-input", mtx, "-output", out, "-iter", "4", "-batch", "16", "-dim", "64", "-option", "5", "-init", out + "start.embd", "-binout", "1"],
+                       cwd=out, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.fromfile(out + "karate.mtxF2VNS16D64IT4NS5.embd.bin", np.float32).reshape(-1, 64)
+    eng = F.Engine(rowptr, colids, 64)
+    eng.srand(1)
+    eng.set_embeddings(X0t)
+    eng.train(5, 4, 16)
+    assert np.array_equal(got, eng.get_embeddings())
+    eng.close()
+    r = subprocess.run([exe, "-input", mtx, "-output", out, "-iter", "1", "-batch", "16", "-dim", "32", "-option", "5", "-init", out + "start.embd"],
+                       cwd=out, capture_output=True, text=True)
+    assert r.returncode == 2 and "-init" in r.stderr                          # another -dim than the file's
+
+
 def test_rmat20_full_size_properties(F):
     """BASELINE configs[2] at full size (RMAT scale-20: 1 048 576 vertices, 31.4 M nonzeros, D = 128): two
     engines run one epoch of f2v_train (batch 65536) -> identical bits (determinism); then one more minibatch

@@ -169,6 +169,30 @@ def test_binary_csr_cache_and_binary_embd(tmp_path):
     assert np.array_equal(D.reshape(-1, 16), X)
 
 
+def test_embedding_readers_round_trip(tmp_path):
+    """f2v_read_embd / f2v_read_embd_bin read back what the writers (and the reference's writeToFile) produce: the text form to the
+    printed 6 digits and in ANY row order, the binary form bit for bit; malformed files are refused."""
+    rng = np.random.default_rng(0)
+    X = rng.uniform(-3, 3, (37, 24)).astype(np.float32)
+    txt, binf = str(tmp_path / "x.embd"), str(tmp_path / "x.bin")
+    F.write_embd(txt, X)
+    F.write_embd_bin(binf, X)
+    assert np.array_equal(F.read_embd_bin(binf, 37, 24), X)
+    got = F.read_embd(txt)
+    assert got.shape == X.shape and np.array_equal(got, O.read_embd(txt)) and np.abs(got - X).max() < 5e-5
+    lines = open(txt).read().splitlines()
+    open(txt, "w").write("\n".join([lines[0]] + lines[:0:-1]) + "\n")     # rows in reverse order: ids place them
+    assert np.array_equal(F.read_embd(txt), got)
+    with pytest.raises(F.F2VError):
+        F.read_embd_bin(binf, 37, 25)                                        # not exactly n * dim floats
+    open(txt, "w").write("\n".join(lines[:-1]) + "\n")                        # a row missing
+    with pytest.raises(F.F2VError):
+        F.read_embd(txt)
+    open(txt, "w").write("\n".join([lines[0], lines[1], lines[1]] + lines[3:]) + "\n")  # a row twice
+    with pytest.raises(F.F2VError):
+        F.read_embd(txt)
+
+
 def test_header_is_plain_c_and_links(tmp_path):
     """include/f2v.h is a C header (no C++ or torch types in the signatures) and a C program links against libf2v."""
     src = tmp_path / "t.c"
