@@ -2286,7 +2286,7 @@ int f2v_train(f2v_handle c, int option, uint32_t iters, uint32_t batch, uint32_t
     bool snap = false;
     Rand rng0 = c->rng;
     const uint64_t fast_epoch0 = c->fast_epoch;
-    if (c->recover && c->merge_fin && c->have_x && iters > 0 && subwave_width(c) != 0) {
+    if (c->recover && c->merge_fin && c->have_x && iters > 0) {  // (merge_fin: this handle's launches may hold in-grid waits)
         HIPC(hipSetDevice(c->device));
         int rc = flush_pending(c);
         if (rc != F2V_OK) return rc;
