@@ -913,11 +913,12 @@ def test_rmat20_full_size_properties(F):
     eng.close()
 
 
-@pytest.mark.parametrize("option,batch", [(5, 384), (6, 4096), (5, 1000)])
+@pytest.mark.parametrize("option,batch", [(5, 384), (6, 4096), (5, 1000), (6, 256), (7, 384), (5, 2048)])
 def test_rmat20_chained_minibatches_full_size(F, option, batch):
     """Chained minibatches at the benchmark's size (RMAT scale-20, 1 M vertices, hubs of 64 k neighbours, ~170 minibatches per
     launch at the reference's default batch 384): three epochs give the same bits as one launch per minibatch -- every row of
-    the 512-MB matrix compared -- and a second chained engine the same again (no dependence on timing)."""
+    the 512-MB matrix compared -- and a second chained engine the same again (no dependence on timing).  Batches up to 2048 run in
+    the wide form (round 3: 683 minibatches per launch at batch 384), 4096 in the round-2 form."""
     _need_round_robin_dispatch(F)
     from force2vec_amd.graph import rmat_csr
     rowptr, colids = rmat_csr(20, 16, seed=1)
