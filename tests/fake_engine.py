@@ -51,7 +51,7 @@ class OracleEngine:
         row_lo = lo if row_lo is None else row_lo
         row_hi = hi if row_hi is None else row_hi
         work = self.X.copy()
-        math = {5: 5, 8: 5, 11: 5, 6: 6, 9: 6, 7: 7, 10: 7}[option]
+        math = {5: 5, 8: 5, 11: 5, 6: 6, 9: 6, 7: 7, 10: 10}[option]  # (option 10: option 7 without the division by deg + 1, as the engine)
         O.minibatch(math, self.rowptr, self.colids, work, lo, hi, ids, ns, lr, bs_mode=bs_mode, walks=self.walks,
                     order=self.order, chunk=self.chunk, row_lo=row_lo, row_hi=row_hi)
         rows = np.full((hi - lo, self.dim), np.nan, dtype=np.float32)  # rows of other ranks must arrive by exchange
