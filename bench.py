@@ -701,7 +701,7 @@ def main():
                 tmp = tempfile.NamedTemporaryFile(suffix=".embd", delete=False)
                 tmp.write(f.read())
                 tmp.close()
-                ref = O.read_embd(tmp.name)
+                ref = F.read_embd(tmp.name)
                 os.unlink(tmp.name)
             err = float(np.abs(got - ref).max())
             if not np.array_equal(got, want) or not err < 3e-5:
