@@ -1255,8 +1255,8 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (OPT == 5 ? F2V_WIDE_WAV
     const WJob *gjobs = w.jobs + bd.c;
     const uint32_t n_jobs = bd.d;
     Item it = items[wave * IPW + q];
-    WJob job_mine{};
-    if (threadIdx.x < n_jobs && threadIdx.x < kWideJobsLds) job_mine = gjobs[threadIdx.x];
+    uint4 job_mine = make_uint4(0u, 0u, 0u, 0u);
+    if (threadIdx.x < n_jobs && threadIdx.x < kWideJobsLds) job_mine = *reinterpret_cast<const uint4 *>(&gjobs[threadIdx.x]);
 
     __shared__ float4 slots[PSLOTS + kWideSumSlots][C4];
     constexpr uint32_t kLdsSamples = 8;
@@ -1307,9 +1307,16 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (OPT == 5 ? F2V_WIDE_WAV
         for (int u = 0; u < U; ++u) jpre[u] = ((uint32_t)u < cnt0) ? a.nbr_ids[it.nb + u] : 0u;
     }
     // (the jobs run at the end of the dependency chain's hops: their descriptors wait in LDS, not behind two more global loads)
-    __shared__ WJob ljobs[kWideJobsLds];
-    if (threadIdx.x < n_jobs && threadIdx.x < kWideJobsLds) ljobs[threadIdx.x] = job_mine;
-    auto job_at = [&](uint32_t k) -> WJob { return k < kWideJobsLds ? ljobs[k] : gjobs[k]; };
+    __shared__ __attribute__((aligned(16))) WJob ljobs[kWideJobsLds];
+    if (threadIdx.x < n_jobs && threadIdx.x < kWideJobsLds) *reinterpret_cast<uint4 *>(&ljobs[threadIdx.x]) = job_mine;
+    auto job_at = [&](uint32_t k) -> WJob {  // (decoded from one 16-byte load: a struct picked by a condition ends up in scratch)
+        const uint4 raw = k < kWideJobsLds ? *reinterpret_cast<const uint4 *>(&ljobs[k]) : *reinterpret_cast<const uint4 *>(&gjobs[k]);
+        WJob j;
+        j.src = (uint8_t)raw.x; j.n = (uint8_t)(raw.x >> 8); j.kind = (uint8_t)(raw.x >> 16); j.phase = (uint8_t)(raw.x >> 24);
+        j.pass_len = (uint8_t)raw.y; j.src2 = (uint8_t)(raw.y >> 8); j.n2 = (uint8_t)(raw.y >> 16); j.dst2 = (uint8_t)(raw.y >> 24);
+        j.dst = raw.z; j.row = raw.w;
+        return j;
+    };
     __syncthreads();
     // the workgroup's last job, when it finishes a row alone in its pass (a finisher's): x_i is requested now, not at the end of the hop
     float xi_pre = 0.f;
@@ -1336,13 +1343,20 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (OPT == 5 ? F2V_WIDE_WAV
                 const WJob jb = head;
                 const uint32_t d = threadIdx.x;
                 float *S = reinterpret_cast<float *>(&slots[0][0]);
+                // slots [first, first + n) of this thread's dim, added in order: 8 reads at a time off one base address (n is uniform:
+                // the guards are scalar branches), so that the job costs a dozen registers, not 64
                 auto sum32 = [&](uint32_t first, uint32_t n) -> float {
-                    float v[32];
+                    const float *base = S + (size_t)first * DP + d;
+                    float acc = base[0];
+                    for (uint32_t k0 = 1; k0 < n; k0 += 8u) {
+                        float v[8];
 #pragma unroll
-                    for (uint32_t k = 0; k < 32u; ++k) v[k] = S[(size_t)(first + (k < n ? k : n - 1u)) * DP + d];
-                    float acc = v[0];
+                        for (uint32_t u = 0; u < 8u; ++u)
+                            if (k0 + u < n) v[u] = base[(size_t)(k0 + u) * DP];
 #pragma unroll
-                    for (uint32_t k = 1; k < 32u; ++k) acc = (k < n) ? acc + v[k] : acc;
+                        for (uint32_t u = 0; u < 8u; ++u)
+                            if (k0 + u < n) acc = acc + v[u];
+                    }
                     return acc;
                 };
                 if (d < D) {  // (D is a multiple of 32 in chained launches: a wavefront's quads are live or idle as a whole)
