@@ -263,7 +263,7 @@ def main():
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: self-test of the N>1 plumbing on a one-GPU box (all ranks on device 0, exchange through the host)")
     ap.add_argument("--force-dist", action="store_true", help="drive even a single rank through the multi-GPU path (RCCL group of 1): self-test")
-    ap.add_argument("--extra-batches", type=str, default="256,384,4096,16384,262144", help="N=1: comma list of further batch sizes to time (reported under 'extra')")
+    ap.add_argument("--extra-batches", type=str, default="256,384,1024,2048,4096,16384,262144", help="N=1: comma list of further batch sizes to time (reported under 'extra')")
     ap.add_argument("--dist-extra-batches", type=str, default="262144", help="N>1: the same for the sharded run (fewer, larger exchanges)")
     ap.add_argument("--verify-rows", type=int, default=32, help="N=1: sampled rows of one more minibatch checked against the CPU oracle after the timed region (0 = skip)")
     ap.add_argument("--config5-scale", type=int, default=24, help="also measure BASELINE configs[4] (RMAT of this scale, option 11) and report it under 'extra' (0 = skip)")
