@@ -181,7 +181,7 @@ def verify_rows(F, eng, rowptr, colids, args, n_rows=32):
     return int(len(rows))
 
 
-def kernel_name(args, pushing, form):
+def kernel_name(args, pushing, form, wide_width=0):
     """The step kernel the last f2v_train of this shape launched: `form` is the engine's own answer ("last_train_form": 0 one
     launch per minibatch, 1 chained, 2 chained in the wide form) -- the launch rules live in f2v_engine.hip, not here."""
     if args.dim % 4 or args.dim > 256:
@@ -189,6 +189,8 @@ def kernel_name(args, pushing, form):
     w = 16
     while w < args.dim:
         w <<= 1
+    if form == 2 and wide_width:
+        w = max(w, wide_width)  # the wide form may run narrow rows on a wider layout ("wide_min_width")
     opt, lpi, nb, u, full = 5 if args.option in (5, 8, 11) else 6, min(16, w // 4), max(1, w // 64), 4 if w >= 128 else 8, "true" if w == args.dim else "false"
     if form == 2 and not pushing:
         return "f2v::qwide_chain_kernel<%d, %d, %d, %d, %s>" % (opt, lpi, nb, u, full)
@@ -563,6 +565,7 @@ def main():
     dt, st, verified = measure(sess, args.steps, args.warmup, args.batch, tune=True)
     main_settle = state["settle_epochs"]
     main_form = eng.get_param("last_train_form")
+    main_wide_width = eng.get_param("last_wide_width") if main_form == 2 else 0
     note(rank, "timed region done: %.3f ms per epoch" % (dt / args.steps * 1e3))
     # rForce2Vec attracts along 5 walk samples per vertex, not along the CSR's nonzeros
     units = 5 * n if args.option in (7, 10) else nnz
@@ -599,7 +602,7 @@ def main():
         t_launch = (st["device_seconds"] if st["device_seconds"] else dt) / launches
         comp = st["compulsory_bytes"] / launches
         alg = st["algorithmic_bytes"] / launches
-        kname = kernel_name(args, use_dist and world > 1 and state["exchange"] == "push" and eng.get_param("push_fused"), main_form)
+        kname = kernel_name(args, use_dist and world > 1 and state["exchange"] == "push" and eng.get_param("push_fused"), main_form, main_wide_width)
         ach = comp / t_launch * 1e-9
         roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                 "kernel": kname, "compulsory_bytes": comp, "compulsory_bytes_per_launch": comp, "avg_launch_us": t_launch * 1e6, "launches": st["step_launches"],

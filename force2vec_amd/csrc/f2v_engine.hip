@@ -74,6 +74,7 @@ struct WidePlan {
     uint64_t nnz = 0, compulsory = 0;
     uint32_t n_hubs = 0, n_chunks = 0;
     uint32_t n_helpers = 0, n_finishers = 0, n_packed = 0, n_node_wgs = 0;  // workgroups by role
+    uint32_t width = 0;  // the sub-wave layout its programs are laid out for (wide_width)
 };
 
 // what a rank hands its peers (f2v_push_export): F2V_PUSH_EXPORT_BYTES bytes
@@ -113,6 +114,7 @@ struct f2v_ctx {
     bool unit_degi = false;  // the option being run is 10 (StepArgs::unit_degi): set by every entry point that takes an option
     uint32_t mark_every = 0;       // "epoch_marks"
     std::vector<double> marks;     // f2v_train_marks
+    uint32_t last_wide_width = 0;  // the layout width of the last wide-form f2v_train ("last_wide_width")
     int last_train_form = 0;  // how the last f2v_train launched: 0 one launch per minibatch, 1 chained, 2 chained in the wide form ("last_train_form")
     bool plan_overflow = false;  // a launch plan needed more than 2^28 partial-sum slots (kItemSlotMask)
     uint32_t *h_kerr = nullptr;  // pinned: the kernel error words as of the last completed epoch-end copy (train_impl)
@@ -149,6 +151,7 @@ struct f2v_ctx {
     uint32_t wide_rows = 262144;     // rows one launch of the wide form covers ("chain_rows" is the HBM form's)
     uint32_t wide_order = 0;    // workgroups of a minibatch: 0 helpers, finishers, packed rows; 1 helpers, packed, finishers; 2 packed, helpers, finishers
     uint32_t wide_phases = 1;   // phases (of 32 piece slots) a workgroup of small rows runs
+    uint32_t wide_min_width = 0;   // "wide_min_width" (wide_width; 0: chosen from the graph and the batch)
     uint32_t wide_rounds = 0;   // rounds per phase of such a workgroup (0: one for minibatches of up to 512 rows, else as many as fill the piece slots)
     uint32_t wide_span = 2;     // fan-in groups per helper workgroup
     uint32_t wide_finish = 4;   // fan-in groups the finisher workgroup keeps for itself (the ones that wait longest)
@@ -500,6 +503,19 @@ uint32_t chain_len(const f2v_ctx *c, uint32_t batch, bool wide_form = false) {
     return (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(k, 1));
 }
 
+// The sub-wave layout the wide form runs a D on.  Narrow rows on a wider layout leave part of every lane group idle, but a
+// wavefront then holds fewer items -- and a wavefront of a chained launch is as late as the latest of its items.  Measured
+// (tools/wide_min_width.py, tools/cora_configs.py): cora at D = 16, 1200 epochs: 0.098 s on the 16-wide layout (16 items per
+// wavefront), 0.086 s on 32, 0.0795 s on 64 (4 items); RMAT-20 at D = 16: 32 wide is 10 % faster than 16 at batch 256 and 17 %
+// slower at 2048, 64 wide slower everywhere (throughput counts there).  "wide_min_width" = 0 chooses: 64 for small graphs (up to
+// 2 M nonzeros), 32 for minibatches of up to 1024 rows, else the narrowest layout that holds D.  The zero padding of the wider
+// tree changes no bit.
+uint32_t wide_width(const f2v_ctx *c, uint32_t batch) {
+    const uint32_t floor_w = c->wide_min_width ? c->wide_min_width : (c->nnz <= (2ull << 20) ? 64u : batch <= 1024u ? 32u : 16u);
+    return std::max(subwave_width(c), floor_w);
+}
+uint32_t wide_items_per_block(uint32_t width) { return 4u * (width == 16 ? 16u : width == 32 ? 8u : 4u); }
+
 // the wide form of a chained launch: jobs add at most 32 LDS slots, so the fan-in groups must fit
 bool wide_usable(const f2v_ctx *c) { return c->wide && c->fanin >= 2 && c->fanin <= 32 && c->waves_per_block == 4; }
 
@@ -648,10 +664,12 @@ const WidePlan &wide_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t batc
     auto itp = c->wides.find(key);
     if (itp != c->wides.end()) return itp->second;
     if (c->h_items.size() > plan_cache_limit(c)) drop_plans(c);
-    const uint32_t ipb = items_per_block(c);                  // lane groups per workgroup = items per round
+    const uint32_t layout = wide_width(c, batch);
+    const uint32_t ipb = wide_items_per_block(layout);        // lane groups per workgroup = items per round
     const uint32_t pslots = std::max<uint32_t>(ipb, 32u);      // piece slots of a phase (PSLOTS of the kernel)
     const uint32_t F = c->fanin;
     WidePlan p;
+    p.width = layout;
     p.first_batch = b0;
     p.n_batches = K;
     p.item_off = c->h_items.size();
@@ -1413,7 +1431,7 @@ int launch_wide(f2v_ctx *c, int math, const WidePlan &plan, const uint32_t *d_id
     wa.jobs = c->d_jobs + plan.job_off;
     wa.ids = d_ids_epoch;
     wa.ids_stride = ids_stride;
-    const uint32_t width = subwave_width(c);
+    const uint32_t width = plan.width;
     const bool full = width == c->D;
     const int o = (math == 5) ? 5 : 6;
 #define F2V_W2(OPT, LPI, NB, U, FULL) hipLaunchKernelGGL((qwide_chain_kernel<OPT, LPI, NB, U, FULL>), dim3(plan.n_wgs), dim3(256), 0, c->stream, wa)
@@ -1953,6 +1971,16 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
         c->chain_max_batch = (uint32_t)value;
         return F2V_OK;
     }
+    if (!strcmp(name, "wide_min_width")) {
+        if (value != 0 && value != 16 && value != 32 && value != 64 && value != 128) return fail(F2V_EINVAL, "wide_min_width must be 0 (automatic), 16, 32, 64 or 128");
+        HIPC(hipSetDevice(c->device));
+        int rc = flush_pending(c);
+        if (rc != F2V_OK) return rc;
+        HIPC(hipStreamSynchronize(c->stream));
+        c->wide_min_width = (uint32_t)value;
+        drop_plans(c);
+        return F2V_OK;
+    }
     if (!strcmp(name, "wide_max_batch")) {
         if (value < 0 || value > 0xFFFFFFFFll) return fail(F2V_EINVAL, "wide_max_batch out of range");
         c->wide_max_batch = (uint32_t)value;
@@ -2061,12 +2089,14 @@ int f2v_get_param(f2v_handle c, const char *name, int64_t *out) {
     if (!strcmp(name, "epoch_marks")) { *out = c->mark_every; return F2V_OK; }
     if (!strcmp(name, "wide_phases")) { *out = c->wide_phases; return F2V_OK; }
     if (!strcmp(name, "wide_max_batch")) { *out = c->wide_max_batch; return F2V_OK; }
+    if (!strcmp(name, "wide_min_width")) { *out = c->wide_min_width; return F2V_OK; }
     if (!strcmp(name, "wide_rows")) { *out = c->wide_rows; return F2V_OK; }
     if (!strcmp(name, "wide_span")) { *out = c->wide_span; return F2V_OK; }
     if (!strcmp(name, "wide_order")) { *out = c->wide_order; return F2V_OK; }
     if (!strcmp(name, "wide_rounds")) { *out = c->wide_rounds; return F2V_OK; }
     if (!strcmp(name, "wide_finish")) { *out = c->wide_finish; return F2V_OK; }
     if (!strcmp(name, "last_train_form")) { *out = c->last_train_form; return F2V_OK; }
+    if (!strcmp(name, "last_wide_width")) { *out = c->last_wide_width; return F2V_OK; }
     if (!strcmp(name, "recover")) { *out = c->recover ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "recoveries")) { *out = c->recoveries; return F2V_OK; }
     if (!strcmp(name, "chain_max_batch")) { *out = c->chain_max_batch; return F2V_OK; }
@@ -2372,6 +2402,7 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
     const bool wide = chained && wide_usable(c) && batch <= c->wide_max_batch && chain_len(c, batch, true) >= 2;
     const uint32_t K = chained ? chain_len(c, batch, wide) : 1;
     c->last_train_form = wide ? 2 : chained ? 1 : 0;
+    if (wide) c->last_wide_width = wide_width(c, batch);
     if (wide) {
         for (uint32_t b0 = 0; b0 < nb; b0 += K) (void)wide_plan_for(c, b0, std::min(K, nb - b0), batch, math == 7);
     } else if (chained) {
