@@ -72,7 +72,11 @@ int f2v_get_embeddings(f2v_handle h, float *x_out);
  * run ("recoveries" counts them), never into a hang or a wrong result.  Set both to 0 where the card is shared on purpose; f2v_create selects 0 by itself when its dispatch probe does not
  * find 8 XCDs taking workgroups round robin ("xcc_count", "xcc_round_robin" answer what it saw); "chain_batches" (default 1): f2v_train runs minibatches of up to "chain_max_batch" (4096) rows in groups of
  * "chain_rows" (65536) rows per launch, ordered by row-level data dependencies inside the launch instead of launch boundaries
- * (same results; batch 256 on RMAT-20: 0.60 -> 2.0 G edges/s); "class_cut" (default 1): a split row's pieces also end where its ascending neighbour ids cross
+ * (same results; batch 256 on RMAT-20: 0.60 -> 2.0 G edges/s); "chain_wide" (default 1): minibatches of up to "wide_max_batch" (2048) rows run
+ * in the WIDE form of such launches -- the pieces of a split row meet in LDS inside one workgroup (finisher + helpers) instead of travelling
+ * through HBM and combine-tree nodes, "wide_rows" (262144) rows per launch; same pieces, same fan-in groups, same results (batch 256: 2.0 -> 4.3 G
+ * edges/s); needs 2 <= "hub_fanin" <= 32; "wide_phases", "wide_rounds", "wide_span", "wide_finish", "wide_min_width" (0 = automatic) shape its
+ * workgroup programs; "last_train_form" answers how the last f2v_train launched (0 one launch per minibatch, 1 chained, 2 wide); "class_cut" (default 1): a split row's pieces also end where its ascending neighbour ids cross
  * from one eighth of the id range into the next (part of the summation order, restated by the oracle; it is what makes
  * "piece_affinity" pure); "piece_affinity" (default 1): a split row's pieces run on the XCD that owns
  * the id range of their neighbours, so that each of the eight L2s caches its own eighth of the matrix (placement only:
