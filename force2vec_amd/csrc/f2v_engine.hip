@@ -2874,6 +2874,177 @@ int f2v_test_chain_nowait(f2v_handle c, int on) {
     return F2V_OK;
 }
 
+// Host-only check of the wide form's launch plans (no device is touched): builds the programs of one epoch for a graph and a
+// set of tunables exactly as f2v_train would and verifies what the kernel relies on --
+//   * every row is finished exactly once (by a whole-row item, a row job, or the root of a combine tree), every neighbour of a
+//     split row belongs to exactly one piece, first / last pieces are flagged as such;
+//   * a workgroup's items fill whole rounds, the items of a round agree on whether it ends a phase, piece slots and job ranges
+//     stay inside the LDS slot space, passes hold at most 8 jobs, a job adds consecutive pieces of ONE row in neighbour order;
+//   * WAITS ONLY POINT BACKWARDS: a helper's group sum is produced by a workgroup with a smaller index than the finisher that
+//     imports it, every sum a combine-tree node adds by a smaller index than the node's, minibatches appear in order.
+// stats_out[0..5]: workgroups, helpers, finishers, packed workgroups, node workgroups, partial-sum slots.
+int f2v_test_wide_plan_check(const uint32_t *rowptr, const uint32_t *colids, uint32_t n, uint64_t nnz, uint32_t dim, uint32_t batch, int walk,
+                             const char *const *names, const int64_t *values, uint32_t n_params, uint64_t *stats_out) {
+    if (!rowptr || (!colids && nnz) || n < 2 || dim == 0 || batch == 0) return fail(F2V_EINVAL, "f2v_test_wide_plan_check: bad argument");
+    f2v_ctx ctx;
+    f2v_ctx *c = &ctx;
+    c->n = n; c->nnz = nnz; c->D = dim;
+    c->rowptr.assign(rowptr, rowptr + n + 1);
+    c->colids.assign(colids, colids + nnz);
+    c->chunk = auto_chunk(c, batch);
+    for (uint32_t k = 0; k < n_params; k++) {
+        const std::string nm = names[k];
+        const int64_t v = values[k];
+        if (nm == "hub_chunk") c->chunk = (uint32_t)v;
+        else if (nm == "hub_fanin") c->fanin = (uint32_t)v;
+        else if (nm == "class_cut") c->class_cut = v != 0;
+        else if (nm == "wide_phases") c->wide_phases = (uint32_t)v;
+        else if (nm == "wide_rounds") c->wide_rounds = (uint32_t)v;
+        else if (nm == "wide_span") c->wide_span = (uint32_t)v;
+        else if (nm == "wide_finish") c->wide_finish = (uint32_t)v;
+        else if (nm == "wide_order") c->wide_order = (uint32_t)v;
+        else if (nm == "wide_rows") c->wide_rows = (uint32_t)v;
+        else if (nm == "wide_min_width") c->wide_min_width = (uint32_t)v;
+        else return fail(F2V_EINVAL, "f2v_test_wide_plan_check: unknown parameter '%s'", nm.c_str());
+    }
+    if (!wide_usable(c) || subwave_width(c) == 0) return fail(F2V_EINVAL, "f2v_test_wide_plan_check: the wide form does not run this shape");
+    const uint32_t nb = (uint32_t)(((uint64_t)n + batch - 1) / batch), K = chain_len(c, batch, true);
+    const uint32_t width = wide_width(c, batch), ipb = wide_items_per_block(width), pslots = std::max<uint32_t>(ipb, 32u), F = c->fanin;
+    std::vector<uint32_t> finished(n, 0), covered(nnz, 0);
+    uint64_t st[6] = {};
+#define F2V_PLAN_FAIL(...) return fail(F2V_ESTATE, "f2v_test_wide_plan_check: " __VA_ARGS__)
+    for (uint32_t b0 = 0; b0 < nb; b0 += K) {
+        const WidePlan p = wide_plan_for(c, b0, std::min(K, nb - b0), batch, walk != 0);
+        if (c->plan_overflow) F2V_PLAN_FAIL("slot overflow");
+        st[0] += p.n_wgs; st[1] += p.n_helpers; st[2] += p.n_finishers; st[3] += p.n_packed; st[4] += p.n_node_wgs; st[5] = std::max<uint64_t>(st[5], p.n_slots);
+        // partial-sum slot -> who announces it: 4 * workgroup + wavefront for a tree node (one node per wavefront: a node may wait for an
+        // earlier wavefront of its own workgroup -- they are resident together), 4 * workgroup + 3 for a job (its consumer must be a LATER workgroup)
+        std::vector<int64_t> producer(p.n_slots + 1, -1);
+        uint32_t last_lo = 0;
+        // pass 1: who produces which slot
+        for (uint32_t wgi = 0; wgi < p.n_wgs; wgi++) {
+            const WideDesc &d = c->h_wide[p.wg_off + wgi];
+            if (d.kind == 0) {
+                for (uint32_t j = 0; j < d.d; j++) {
+                    const WJob &jb = c->h_jobs[p.job_off + d.c + j];
+                    if (jb.kind == kJobPart) {
+                        if (jb.dst >= p.n_slots || producer[jb.dst] != -1) F2V_PLAN_FAIL("partial-sum slot %u produced twice or out of range", jb.dst);
+                        producer[jb.dst] = 4 * (int64_t)wgi + 3;
+                    }
+                }
+            } else {
+                for (uint32_t w = 0; w < 4 && d.c * 4 + w < d.b; w++) {
+                    const FinItem &h = c->h_hubs[p.fin_off + d.a + d.c * 4 + w];
+                    if (h.n == 0) continue;
+                    if (h.out != kFinToStage) {
+                        if (h.out >= p.n_slots || producer[h.out] != -1) F2V_PLAN_FAIL("tree node output slot %u produced twice or out of range", h.out);
+                        producer[h.out] = 4 * (int64_t)wgi + w;
+                    }
+                }
+            }
+        }
+        // pass 2: every workgroup
+        for (uint32_t wgi = 0; wgi < p.n_wgs; wgi++) {
+            const WideDesc &d = c->h_wide[p.wg_off + wgi];
+            if (d.lo < last_lo || d.lo < p.lo || d.lo >= p.hi) F2V_PLAN_FAIL("workgroup %u: minibatch at row %u out of order", wgi, d.lo);
+            last_lo = d.lo;
+            const uint32_t mb_hi = (uint32_t)std::min<uint64_t>((uint64_t)d.lo + batch, n);
+            if (d.kind == 1) {
+                for (uint32_t w = 0; w < 4 && d.c * 4 + w < d.b; w++) {
+                    const FinItem &h = c->h_hubs[p.fin_off + d.a + d.c * 4 + w];
+                    if (h.n == 0) continue;
+                    for (uint32_t k = 0; k < h.n; k++)
+                        if (h.in_slot + k >= p.n_slots || producer[h.in_slot + k] < 0 || producer[h.in_slot + k] >= 4 * (int64_t)wgi + w)
+                            F2V_PLAN_FAIL("tree node of row %u (workgroup %u) adds slot %u whose producer is not an earlier workgroup (or an earlier wavefront of its own)", h.row, wgi, h.in_slot + k);
+                    if (h.out == kFinToStage) {
+                        if (h.row < d.lo || h.row >= mb_hi) F2V_PLAN_FAIL("tree root of row %u outside its minibatch", h.row);
+                        finished[h.row]++;
+                    }
+                }
+                continue;
+            }
+            const Item *items = c->h_items.data() + p.item_off + d.a;
+            const WJob *jobs = c->h_jobs.data() + p.job_off + d.c;
+            if (d.b == 0) F2V_PLAN_FAIL("workgroup %u has no round", wgi);
+            // phases: rounds up to a round whose items carry kItemPhaseEnd
+            std::vector<std::vector<const Item *>> phase_items(1);
+            for (uint32_t r = 0; r < d.b; r++) {
+                const bool end = (items[(size_t)r * ipb].flags & kItemPhaseEnd) != 0;
+                for (uint32_t q = 0; q < ipb; q++) {
+                    const Item &it = items[(size_t)r * ipb + q];
+                    if (((it.flags & kItemPhaseEnd) != 0) != end) F2V_PLAN_FAIL("workgroup %u round %u: items disagree about the end of the phase", wgi, r);
+                    if (it.flags & kItemIdle) continue;
+                    if (it.row < d.lo || it.row >= mb_hi) F2V_PLAN_FAIL("workgroup %u: row %u outside its minibatch [%u,%u)", wgi, it.row, d.lo, mb_hi);
+                    if (!walk) {
+                        if (it.nb < rowptr[it.row] || it.nb + it.cnt > rowptr[it.row + 1]) F2V_PLAN_FAIL("row %u: piece outside the row's neighbours", it.row);
+                        for (uint32_t e = 0; e < it.cnt; e++) covered[it.nb + e]++;
+                        if (((it.flags & kItemFirst) != 0) != (it.nb == rowptr[it.row]) || ((it.flags & kItemLast) != 0) != (it.nb + it.cnt == rowptr[it.row + 1]))
+                            F2V_PLAN_FAIL("row %u: first / last flags of a piece are wrong", it.row);
+                    }
+                    if (it.flags & kItemDirect) finished[it.row]++;
+                    else if ((it.flags & kItemPieceSlot) >= pslots) F2V_PLAN_FAIL("row %u: piece slot out of range", it.row);
+                    phase_items.back().push_back(&it);
+                }
+                if (end && r + 1 < d.b) phase_items.emplace_back();
+                if (!end && r + 1 == d.b) F2V_PLAN_FAIL("workgroup %u: the last round does not end a phase", wgi);
+            }
+            uint32_t last_phase = 0;
+            bool before_ok = true;
+            for (uint32_t j = 0; j < d.d; j++) {
+                const WJob &jb = jobs[j];
+                if (jb.pass_len == 0 || jb.pass_len > 8) F2V_PLAN_FAIL("workgroup %u: a pass of %u jobs", wgi, jb.pass_len);
+                if (jb.phase == kJobBefore) { if (!before_ok) F2V_PLAN_FAIL("workgroup %u: a before-the-first-round job behind a phase job", wgi); }
+                else {
+                    before_ok = false;
+                    if (jb.phase < last_phase || jb.phase >= phase_items.size()) F2V_PLAN_FAIL("workgroup %u: job phases out of order", wgi);
+                    last_phase = jb.phase;
+                }
+                if (jb.kind == kJobImport) {
+                    if (jb.dst < pslots || jb.dst >= pslots + kWideSumSlots) F2V_PLAN_FAIL("workgroup %u: an import lands outside the sum slots", wgi);
+                    if (jb.row >= p.n_slots || producer[jb.row] < 0 || producer[jb.row] >= 4 * (int64_t)wgi)
+                        F2V_PLAN_FAIL("workgroup %u imports slot %u whose producer is not an earlier workgroup", wgi, jb.row);
+                    continue;
+                }
+                if (jb.n == 0 || (uint32_t)jb.src + jb.n > pslots + kWideSumSlots) F2V_PLAN_FAIL("workgroup %u: a job's slots are out of range", wgi);
+                // piece-slot ranges: consecutive pieces of ONE row, in neighbour order, all in the job's phase
+                auto check_pieces = [&](uint32_t first, uint32_t cnt, uint32_t row) -> bool {
+                    if (first + cnt > pslots || jb.phase == kJobBefore) return false;
+                    uint32_t next_nb = 0;
+                    for (uint32_t k = 0; k < cnt; k++) {
+                        const Item *hit = nullptr;
+                        for (const Item *it : phase_items[jb.phase])
+                            if (!(it->flags & kItemDirect) && (it->flags & kItemPieceSlot) == first + k) { if (hit) return false; hit = it; }
+                        if (!hit || hit->row != row || (k && hit->nb != next_nb)) return false;
+                        next_nb = hit->nb + hit->cnt;
+                    }
+                    return true;
+                };
+                if (jb.n2 != 0) {
+                    if (jb.dst2 < jb.src || jb.dst2 >= (uint32_t)jb.src + jb.n || jb.pass_len != 1) F2V_PLAN_FAIL("workgroup %u: a fused job's first sum does not land among its second's slots", wgi);
+                    if (!walk && !check_pieces(jb.src2, jb.n2, jb.row)) F2V_PLAN_FAIL("row %u: a fused job's pieces are not consecutive pieces of the row", jb.row);
+                }
+                if (jb.src < pslots) {
+                    if (jb.n > F) F2V_PLAN_FAIL("row %u: a job adds %u pieces, more than the fan-in", jb.row, jb.n);
+                    if (!walk && !check_pieces(jb.src, jb.n, jb.row)) F2V_PLAN_FAIL("row %u: a job's pieces are not consecutive pieces of the row", jb.row);
+                }
+                if (jb.kind == kJobLds && (jb.dst < pslots || jb.dst >= pslots + kWideSumSlots)) F2V_PLAN_FAIL("workgroup %u: a group sum lands outside the sum slots", wgi);
+                if (jb.kind == kJobRow) {
+                    if (jb.row < d.lo || jb.row >= mb_hi) F2V_PLAN_FAIL("row job of row %u outside its minibatch", jb.row);
+                    finished[jb.row]++;
+                }
+            }
+        }
+    }
+#undef F2V_PLAN_FAIL
+    for (uint32_t i = 0; i < n; i++)
+        if (finished[i] != 1) return fail(F2V_ESTATE, "f2v_test_wide_plan_check: row %u is finished %u times", i, finished[i]);
+    if (!walk)
+        for (uint64_t e = 0; e < nnz; e++)
+            if (covered[e] != 1) return fail(F2V_ESTATE, "f2v_test_wide_plan_check: neighbour %llu is in %u pieces", (unsigned long long)e, covered[e]);
+    if (stats_out) memcpy(stats_out, st, sizeof st);
+    return F2V_OK;
+}
+
 int f2v_test_stamps(f2v_handle c, int on, unsigned long long *out) {
     if (!c) return fail(F2V_EINVAL, "null handle");
     HIPC(hipSetDevice(c->device));
