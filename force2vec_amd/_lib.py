@@ -75,6 +75,7 @@ SIGNATURES = {
     "f2v_rng_next": (C.c_int, [C.c_void_p]),
     "f2v_rng_jump": (None, [C.c_void_p, C.c_uint64]),
     "f2v_rng_fill": (C.c_int, [C.c_void_p, f32p, C.c_uint64, C.c_int]),
+    "f2v_rng_walks": (C.c_int, [C.c_void_p, u32p, u32p, C.c_uint32, C.c_uint64, u32p]),
     "f2v_sm_table": (C.c_int, [f32p]),
     "f2v_diag_ipc_preflight": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint64, C.c_double]),
     "f2v_diag_stream_copy": (C.c_int, [C.c_int, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),

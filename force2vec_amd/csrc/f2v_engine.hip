@@ -1462,24 +1462,9 @@ int launch_wide(f2v_ctx *c, int math, const WidePlan &plan, const uint32_t *d_id
 }
 
 void generate_walks_host(f2v_ctx *c, std::vector<uint32_t> &walks) {
-    // sample/algorithms.cpp:1097-1118.  deg>2: a random neighbour except the last; deg==2: the first;
-    // otherwise colids[w] with the VERTEX id as edge index (kept for parity; clamped to the array).
+    // sample/algorithms.cpp:1097-1118, from the handle's rand() stream (f2v_host.cpp: walks_host)
     walks.resize((size_t)c->n * kWalkLength);
-    const uint32_t *rp = c->rowptr.data(), *ci = c->colids.data();
-    for (uint32_t i = 0; i < c->n; i++) {
-        uint32_t w = i;
-        for (int s = 0; s < kWalkLength; s++) {
-            uint32_t j = w;
-            const uint32_t deg = rp[w + 1] - rp[w];
-            if (deg > 2)
-                j = c->rng.index(rp[w + 1] - 1, rp[w]);
-            else if (deg == 2)
-                j = rp[w];
-            if ((uint64_t)j >= c->nnz) j = (uint32_t)(c->nnz ? c->nnz - 1 : 0);
-            walks[(size_t)i * kWalkLength + s] = ci[j];
-            w = ci[j];
-        }
-    }
+    walks_host(c->rng, c->rowptr.data(), c->colids.data(), c->n, c->nnz, walks.data());
 }
 
 // ---- push exchange helpers (include/f2v.h) ---------------------------------------------------------------

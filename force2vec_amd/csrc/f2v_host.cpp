@@ -141,6 +141,81 @@ void sm_table_host(float *t) {
     }
 }
 
+// Option 7's walks (sample/algorithms.cpp:1097-1118): from every vertex five steps -- degree > 2: a random neighbour except the
+// last (ONE rand() draw); degree 2: the first neighbour; otherwise colids[w] with the VERTEX id as edge index (kept for parity,
+// clamped to the array) -- each step's target is a sample and the next step's start.  rand() is drawn only at vertices of
+// degree > 2, so where a walk's draws lie in the stream depends on every walk before it: the reference's loop is one chain of
+// dependent cache misses (35 ns a step on RMAT-20).  Here 32 consecutive walks run side by side, step by step, every access
+// prefetched a pass ahead, from stream positions PREDICTED for them (a draw at every step but those whose degree is known
+// beforehand: the start vertex, and the second vertex where the first step draws nothing); afterwards the draws each walk really
+// made are compared with the prediction, the walks up to and including the first mispredicted one are kept -- they started at
+// the right position -- and the block restarts behind it.  Same samples, same stream position afterwards (draws taken ahead are
+// given back, Rand::back), whatever the graph.
+#ifndef F2V_WALK_BLOCK
+#define F2V_WALK_BLOCK 32  // RMAT-20, 5.2 M steps: 8 / 16 / 32 / 64 / 128 walks side by side -> 210 / 178 / 168 / 205 / 350 ms where the serial loop takes 530
+#endif
+void walks_host(Rand &g, const uint32_t *rp, const uint32_t *ci, uint32_t n, uint64_t nnz, uint32_t *walks) {
+    constexpr uint32_t B = F2V_WALK_BLOCK, L = (uint32_t)kWalkLength, V = B * L;
+    if (nnz == 0) {  // no vertex has a neighbour: nothing is drawn (the reference would read colids[0] of an empty array)
+        for (size_t k = 0; k < (size_t)n * L; k++) walks[k] = 0;
+        return;
+    }
+    const uint32_t last = (uint32_t)(nnz - 1);
+    uint32_t vals[V];
+    uint32_t avail = 0;  // vals[0, avail): the stream's next draws
+    uint32_t w[B], jj[B], off[B], used[B], predicted[B];
+    for (uint32_t i0 = 0; i0 < n;) {
+        const uint32_t nb = std::min(B, n - i0);
+        while (avail < V) vals[avail++] = (uint32_t)g.next();
+        // predicted draws per walk
+        for (uint32_t t = 0; t < nb; t++) {
+            const uint32_t i = i0 + t, deg = rp[i + 1] - rp[i];
+            w[t] = i;
+            used[t] = 0;
+            if (deg > 2) {
+                predicted[t] = L;
+                jj[t] = 0xFFFFFFFFu;
+            } else {
+                const uint32_t j = std::min(deg == 2 ? rp[i] : i, last);
+                jj[t] = ci[j];  // the second vertex, known without a draw
+                __builtin_prefetch(rp + jj[t]);
+            }
+        }
+        uint32_t at = 0;
+        for (uint32_t t = 0; t < nb; t++) {
+            if (jj[t] != 0xFFFFFFFFu) predicted[t] = (L - 2) + (rp[jj[t] + 1] - rp[jj[t]] > 2 ? 1u : 0u);
+            off[t] = at;
+            at += predicted[t];
+        }
+        for (uint32_t s = 0; s < L; s++) {
+            for (uint32_t t = 0; t < nb; t++) {
+                const uint32_t v = w[t], lo = rp[v], deg = rp[v + 1] - lo;
+                uint32_t j = v;
+                if (deg > 2) j = vals[off[t] + used[t]++] % (deg - 1) + lo;  // randIndex(rowptr[v+1] - 1, rowptr[v])
+                else if (deg == 2) j = lo;
+                if (j > last) j = last;
+                jj[t] = j;
+                __builtin_prefetch(ci + j);
+            }
+            for (uint32_t t = 0; t < nb; t++) {
+                const uint32_t v = ci[jj[t]];
+                walks[(size_t)(i0 + t) * L + s] = v;
+                w[t] = v;
+                __builtin_prefetch(rp + v);
+            }
+        }
+        uint32_t valid = nb, consumed = 0;
+        for (uint32_t t = 0; t < nb; t++) {
+            consumed += used[t];
+            if (used[t] != predicted[t]) { valid = t + 1; break; }
+        }
+        avail -= consumed;
+        memmove(vals, vals + consumed, avail * sizeof(uint32_t));
+        i0 += valid;
+    }
+    while (avail--) g.back();
+}
+
 }  // namespace f2v
 
 using namespace f2v;
@@ -161,6 +236,15 @@ void f2v_rng_jump(f2v_rng *g, uint64_t k) { reinterpret_cast<Rand *>(g)->jump(k)
 int f2v_rng_fill(f2v_rng *g, float *out, uint64_t count, int kind) {
     if (!g || (!out && count) || (kind != F2V_INIT_SYMMETRIC && kind != F2V_INIT_UNIT)) return fail(F2V_EINVAL, "f2v_rng_fill: bad argument");
     init_embeddings_host(*reinterpret_cast<Rand *>(g), out, (size_t)count, kind);
+    return F2V_OK;
+}
+
+int f2v_rng_walks(f2v_rng *g, const uint32_t *rowptr, const uint32_t *colids, uint32_t n, uint64_t nnz, uint32_t *walks_out) {
+    if (!g || !rowptr || (!colids && nnz) || !walks_out) return fail(F2V_EINVAL, "f2v_rng_walks: null argument");
+    if (rowptr[0] != 0 || rowptr[n] != nnz) return fail(F2V_EINVAL, "f2v_rng_walks: rowptr[0] must be 0 and rowptr[n] == nnz");
+    for (uint64_t k = 0; k < nnz; k++)
+        if (colids[k] >= n) return fail(F2V_EINVAL, "f2v_rng_walks: column id %u outside the graph", colids[k]);
+    walks_host(*reinterpret_cast<Rand *>(g), rowptr, colids, n, nnz, walks_out);
     return F2V_OK;
 }
 

@@ -31,10 +31,18 @@ struct Rand {
     // one 31x31 matrix over Z/2^32 applied to the 31-word state.  This is what lets N*D draws be made in parallel
     // (and bit-identically to the serial stream).
     void jump(uint64_t k);
+    // Take the last draw back (the recurrence is invertible: the word it overwrote is the sum minus the other tap).
+    inline void back() {
+        if (--f < 0) f = 30;
+        if (--b < 0) b = 30;
+        r[f] = (int32_t)((uint32_t)r[f] - (uint32_t)r[b]);
+    }
 };
 
 void init_embeddings_host(Rand &g, float *x, size_t total, int kind);
 void sm_table_host(float *t);
+// One epoch's option-7 walk samples [5*n] drawn from `g` exactly as the reference's serial loop draws them (f2v_host.cpp)
+void walks_host(Rand &g, const uint32_t *rowptr, const uint32_t *colids, uint32_t n, uint64_t nnz, uint32_t *walks);
 
 }  // namespace f2v
 #endif

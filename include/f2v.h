@@ -267,6 +267,10 @@ void f2v_rng_jump(f2v_rng *g, uint64_t k);
  * in parallel from jump-ahead states; the stream ends where `count` serial draws would leave it. */
 int f2v_rng_fill(f2v_rng *g, float *out, uint64_t count, int kind);
 
+/* One epoch's option-7 walk samples uint32[5*n] from stream g, exactly the reference's draws in the reference's order
+ * (sample/algorithms.cpp:1097-1118) -- what f2v_generate_walks does with the handle's own stream, without a device. */
+int f2v_rng_walks(f2v_rng *g, const uint32_t *rowptr, const uint32_t *colids, uint32_t n, uint64_t nnz, uint32_t *walks_out);
+
 /* The 2048-entry sigmoid table of init_SM_TABLE (sample/algorithms.cpp:757-764) as the source defines it. */
 int f2v_sm_table(float *table_out /* 2048 */);
 

@@ -321,3 +321,56 @@ def test_bench_self_launch_propagates_failure():
     assert r.returncode != 0
     assert r.stdout.strip() == "", r.stdout
     assert "torch.distributed.run" in r.stderr
+
+
+def _walk_graphs():
+    """(name, rowptr, colids): real, power-law, and graphs made to defeat the walk generator's predictions"""
+    from force2vec_amd.graph import rmat_csr
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name in ("karate", "cora"):
+        rp, ci = F.read_mtx(os.path.join(here, "golden", name + ".mtx"))
+        yield name, rp, ci
+    rp, ci = rmat_csr(13, 8, 3)
+    yield "rmat13", rp, ci
+    rng = np.random.default_rng(5)
+    # degrees 0..4 mixed at random (draw / no draw alternate unpredictably), ids random: every block mispredicts
+    n = 3000
+    deg = rng.integers(0, 5, size=n)
+    rp = np.concatenate(([0], np.cumsum(deg))).astype(np.uint32)
+    ci = np.concatenate([np.sort(rng.choice(n, size=d, replace=False)) for d in deg] + [np.zeros(0, dtype=np.int64)]).astype(np.uint32)
+    yield "mixed", rp, ci
+    # a ring (every degree 2: nothing is ever drawn), and a graph of one edge among many isolated vertices
+    n = 100
+    ring = np.stack([(np.arange(n) - 1) % n, (np.arange(n) + 1) % n], axis=1)
+    yield "ring", (2 * np.arange(n + 1)).astype(np.uint32), np.sort(ring, axis=1).reshape(-1).astype(np.uint32)
+    rp = np.zeros(41, dtype=np.uint32)
+    rp[8:] = 1
+    rp[31:] = 2
+    yield "one-edge", rp, np.array([30, 7], dtype=np.uint32)
+    # fewer vertices than one block of walks, all of degree 3
+    yield "k4", (3 * np.arange(5)).astype(np.uint32), np.array([1, 2, 3, 0, 2, 3, 0, 1, 3, 0, 1, 2], dtype=np.uint32)
+
+
+def test_walks_from_the_rand_stream_equal_the_reference_loop():
+    """f2v_rng_walks (32 walks side by side from predicted stream positions) = the oracle's serial loop (algorithms.cpp:1097-1118):
+    same samples, and the stream stands where the serial loop leaves it -- two epochs in a row, several seeds."""
+    L = _lib.lib()
+    for name, rp, ci in _walk_graphs():
+        n = len(rp) - 1
+        for seed in (1, 99):
+            g = L.f2v_rng_create(seed)
+            o = O.Rng(seed)
+            for epoch in range(2):
+                want = O.generate_walks(o, rp, ci)
+                got = np.empty(5 * n, dtype=np.uint32)
+                _lib.check(L.f2v_rng_walks(g, rp.ctypes.data_as(_lib.u32p), ci.ctypes.data_as(_lib.u32p), n, len(ci), got.ctypes.data_as(_lib.u32p)))
+                assert np.array_equal(got, want), (name, seed, epoch, int(np.flatnonzero(got != want)[0]))
+                assert [L.f2v_rng_next(g) for _ in range(40)] == [o.rand() for _ in range(40)], (name, seed, epoch)
+            L.f2v_rng_destroy(g)
+    g = L.f2v_rng_create(1)
+    bad = np.array([0, 1, 2], dtype=np.uint32)
+    out = np.empty(10, dtype=np.uint32)
+    off_graph = np.array([1, 5], dtype=np.uint32)  # a column id that is no vertex: refused, nothing drawn
+    assert L.f2v_rng_walks(g, bad.ctypes.data_as(_lib.u32p), off_graph.ctypes.data_as(_lib.u32p), 2, 2, out.ctypes.data_as(_lib.u32p)) == _lib.F2V_EINVAL
+    assert L.f2v_rng_next(g) == O.Rng(1).rand()
+    L.f2v_rng_destroy(g)
