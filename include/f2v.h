@@ -75,8 +75,10 @@ int f2v_get_embeddings(f2v_handle h, float *x_out);
  * (same results; batch 256 on RMAT-20: 0.60 -> 2.0 G edges/s); "chain_wide" (default 1): minibatches of up to "wide_max_batch" (2048) rows run
  * in the WIDE form of such launches -- the pieces of a split row meet in LDS inside one workgroup (finisher + helpers) instead of travelling
  * through HBM and combine-tree nodes, "wide_rows" (262144) rows per launch; same pieces, same fan-in groups, same results (batch 256: 2.0 -> 4.3 G
- * edges/s); needs 2 <= "hub_fanin" <= 32; "wide_phases", "wide_rounds", "wide_span", "wide_finish", "wide_min_width" (0 = automatic) shape its
- * workgroup programs; "last_train_form" answers how the last f2v_train launched (0 one launch per minibatch, 1 chained, 2 wide); "class_cut" (default 1): a split row's pieces also end where its ascending neighbour ids cross
+ * edges/s); needs 2 <= "hub_fanin" <= 32; "wide_phases", "wide_rounds", "wide_span", "wide_finish", "wide_order" (where a minibatch's whole-row
+ * workgroups go: measured neutral), "wide_min_width" (0 = automatic) shape its
+ * workgroup programs; "last_train_form" answers how the last f2v_train launched (0 one launch per minibatch, 1 chained, 2 wide), "last_wide_width"
+ * the sub-wave layout a wide run used; "class_cut" (default 1): a split row's pieces also end where its ascending neighbour ids cross
  * from one eighth of the id range into the next (part of the summation order, restated by the oracle; it is what makes
  * "piece_affinity" pure); "piece_affinity" (default 1): a split row's pieces run on the XCD that owns
  * the id range of their neighbours, so that each of the eight L2s caches its own eighth of the matrix (placement only:
@@ -89,7 +91,8 @@ int f2v_get_embeddings(f2v_handle h, float *x_out);
  * "fast_rng" = 1 selects the NON-PARITY fast mode: initial embeddings and the option-7
  * walks are generated on the device by a counter-based RNG (same distributions, different numbers than
  * the reference's libc rand() stream); negative-sample ids still come from the handle's rand() stream.
- * f2v_get_param also answers "dim", "n", "nnz". */
+ * f2v_get_param also answers "dim", "n", "nnz", "hub_chunk_auto" (1 while the chunk is still chosen per call), and for
+ * a handle attached to a push exchange "push_rank", "push_world", "shared_card" (1: a peer runs on this very GPU). */
 int f2v_set_param(f2v_handle h, const char *name, int64_t value);
 int f2v_get_param(f2v_handle h, const char *name, int64_t *value_out);
 
