@@ -152,6 +152,7 @@ struct f2v_ctx {
     uint32_t wide_order = 0;    // workgroups of a minibatch: 0 helpers, finishers, packed rows; 1 helpers, packed, finishers; 2 packed, helpers, finishers
     uint32_t wide_phases = 1;   // phases (of 32 piece slots) a workgroup of small rows runs
     uint32_t wide_min_width = 0;   // "wide_min_width" (wide_width; 0: chosen from the graph and the batch)
+    int wide_samples_early = -1;  // "wide_samples_early": StepArgs::samples_early; -1 = automatic (graphs of up to 2 M nonzeros: the launch is one dependency chain)
     uint32_t wide_rounds = 0;   // rounds per phase of such a workgroup (0: one for minibatches of up to 512 rows, else as many as fill the piece slots)
     uint32_t wide_span = 2;     // fan-in groups per helper workgroup
     uint32_t wide_finish = 4;   // fan-in groups the finisher workgroup keeps for itself (the ones that wait longest)
@@ -1434,7 +1435,10 @@ int launch_wide(f2v_ctx *c, int math, const WidePlan &plan, const uint32_t *d_id
     const uint32_t width = plan.width;
     const bool full = width == c->D;
     const int o = (math == 5) ? 5 : 6;
-#define F2V_W2(OPT, LPI, NB, U, FULL) hipLaunchKernelGGL((qwide_chain_kernel<OPT, LPI, NB, U, FULL>), dim3(plan.n_wgs), dim3(256), 0, c->stream, wa)
+    // "wide_samples_early" (-1 = automatic): on for graphs of up to 2 M nonzeros, whose launches are one dependency chain
+    const bool early = c->wide_samples_early >= 0 ? c->wide_samples_early != 0 : c->nnz <= (2ull << 20);
+#define F2V_W3(OPT, LPI, NB, U, FULL, EARLY) hipLaunchKernelGGL((qwide_chain_kernel<OPT, LPI, NB, U, FULL, EARLY>), dim3(plan.n_wgs), dim3(256), 0, c->stream, wa)
+#define F2V_W2(OPT, LPI, NB, U, FULL) do { if (early) F2V_W3(OPT, LPI, NB, U, FULL, true); else F2V_W3(OPT, LPI, NB, U, FULL, false); } while (0)
 #define F2V_W(OPT, LPI, NB, U) do { if (full) F2V_W2(OPT, LPI, NB, U, true); else F2V_W2(OPT, LPI, NB, U, false); } while (0)
     switch (width) {
         case 16: if (o == 5) F2V_W(5, 4, 1, 8); else F2V_W(6, 4, 1, 8); break;
@@ -1445,6 +1449,7 @@ int launch_wide(f2v_ctx *c, int math, const WidePlan &plan, const uint32_t *d_id
     }
 #undef F2V_W
 #undef F2V_W2
+#undef F2V_W3
     HIPC(hipGetLastError());
     if (c->upd_hi == c->upd_lo) c->upd_lo = plan.lo;
     c->upd_hi = plan.hi;
@@ -1956,6 +1961,11 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
         c->chain_max_batch = (uint32_t)value;
         return F2V_OK;
     }
+    if (!strcmp(name, "wide_samples_early")) {
+        if (value < -1 || value > 1) return fail(F2V_EINVAL, "wide_samples_early must be -1 (automatic), 0 or 1");
+        c->wide_samples_early = (int)value;
+        return F2V_OK;
+    }
     if (!strcmp(name, "wide_min_width")) {
         if (value != 0 && value != 16 && value != 32 && value != 64 && value != 128) return fail(F2V_EINVAL, "wide_min_width must be 0 (automatic), 16, 32, 64 or 128");
         HIPC(hipSetDevice(c->device));
@@ -2075,6 +2085,7 @@ int f2v_get_param(f2v_handle c, const char *name, int64_t *out) {
     if (!strcmp(name, "wide_phases")) { *out = c->wide_phases; return F2V_OK; }
     if (!strcmp(name, "wide_max_batch")) { *out = c->wide_max_batch; return F2V_OK; }
     if (!strcmp(name, "wide_min_width")) { *out = c->wide_min_width; return F2V_OK; }
+    if (!strcmp(name, "wide_samples_early")) { *out = c->wide_samples_early; return F2V_OK; }
     if (!strcmp(name, "wide_rows")) { *out = c->wide_rows; return F2V_OK; }
     if (!strcmp(name, "wide_span")) { *out = c->wide_span; return F2V_OK; }
     if (!strcmp(name, "wide_order")) { *out = c->wide_order; return F2V_OK; }

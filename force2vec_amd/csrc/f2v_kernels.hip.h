@@ -658,74 +658,81 @@ __device__ __forceinline__ float item_allreduce_tree(float v) {
     return v;
 }
 
+// One (row, other row) interaction in two parts.  pair_coef_q: the pair's scalar -- the t-distribution's d1 (option 5), the
+// attraction's (1 - sigmoid) * c0 in fp64 or the repulsion's lr * sigmoid (options 6, 7) -- which needs x_i and the other row
+// only; pair_apply_q: the other row's contribution added onto Y, which must happen in list order.  pair_update_q is one after the
+// other; the wide chained kernel computes the scalars of the rows that have arrived while it waits for a late one.
+template <int OPT, bool NEG>
+struct PairCoef { using type = float; };
+template <>
+struct PairCoef<6, false> { using type = double; };  // (the kernels' OPT is 5 or 6: option 7 runs option 6's arithmetic on walk samples)
+
 template <int OPT, int LPI, int NB, bool NEG>
-__device__ __forceinline__ void pair_update_q(const float (&xi)[NB][4], const float4 (&xj4)[NB], float (&Y)[NB][4],
-                                              float lr, double c0, const float *table) {
+__device__ __forceinline__ typename PairCoef<OPT, NEG>::type pair_coef_q(const float (&xi)[NB][4], const float4 (&xj4)[NB], float lr, double c0,
+                                                                         const float *table) {
     float xj[NB][4], bs[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         xj[b][0] = xj4[b].x; xj[b][1] = xj4[b].y; xj[b][2] = xj4[b].z; xj[b][3] = xj4[b].w;
     }
-    if constexpr (OPT == 5) {
-        float diff[NB][4];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            float t[4];
+    for (int b = 0; b < NB; ++b) {
+        float t[4];
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                diff[b][v] = xi[b][v] - xj[b][v];
-                t[v] = diff[b][v] * diff[b][v];
+        for (int v = 0; v < 4; ++v) {
+            if constexpr (OPT == 5) {
+                const float d = xi[b][v] - xj[b][v];
+                t[v] = d * d;
+            } else {
+                t[v] = xi[b][v] * xj[b][v];
             }
-            bs[b] = item_allreduce_tree<LPI>((t[0] + t[1]) + (t[2] + t[3]));
         }
-        float a;
-        if constexpr (NB == 1) a = bs[0];
-        else if constexpr (NB == 2) a = bs[0] + bs[1];
-        else a = (bs[0] + bs[1]) + (bs[2] + bs[3]);
-        float d1;
-        if constexpr (NEG)
-            d1 = (float)(2.0 / ((double)a * (1.0 + (double)a)));  // algorithms.cpp:622
-        else
-            d1 = (float)(-2.0 / (1.0 + (double)a));               // algorithms.cpp:608
+        bs[b] = item_allreduce_tree<LPI>((t[0] + t[1]) + (t[2] + t[3]));
+    }
+    float a;
+    if constexpr (NB == 1) a = bs[0];
+    else if constexpr (NB == 2) a = bs[0] + bs[1];
+    else a = (bs[0] + bs[1]) + (bs[2] + bs[3]);
+    if constexpr (OPT == 5) {
+        if constexpr (NEG) return (float)(2.0 / ((double)a * (1.0 + (double)a)));  // algorithms.cpp:622
+        else return (float)(-2.0 / (1.0 + (double)a));                              // algorithms.cpp:608
+    } else {
+        const float sm = fast_sm(table, a);
+        if constexpr (!NEG) return (1.0 - (double)sm) * c0;  // algorithms.cpp:867
+        else return lr * sm;                                  // algorithms.cpp:907
+    }
+}
+
+template <int OPT, int LPI, int NB, bool NEG>
+__device__ __forceinline__ void pair_apply_q(const float (&xi)[NB][4], const float4 (&xj4)[NB], float (&Y)[NB][4], float lr,
+                                             typename PairCoef<OPT, NEG>::type coef) {
+    float xj[NB][4];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
+    for (int b = 0; b < NB; ++b) {
+        xj[b][0] = xj4[b].x; xj[b][1] = xj4[b].y; xj[b][2] = xj4[b].z; xj[b][3] = xj4[b].w;
+    }
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const float f = clamp_ref(diff[b][v] * d1);
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            if constexpr (OPT == 5) {
+                const float f = clamp_ref((xi[b][v] - xj[b][v]) * coef);
                 const float s = lr * f;
                 Y[b][v] = Y[b][v] + s;
+            } else if constexpr (!NEG) {
+                Y[b][v] = (float)((double)xj[b][v] * coef + (double)Y[b][v]);
+            } else {
+                const float p = coef * xj[b][v];
+                Y[b][v] = Y[b][v] - p;
             }
         }
-    } else {
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            float t[4];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) t[v] = xi[b][v] * xj[b][v];
-            bs[b] = item_allreduce_tree<LPI>((t[0] + t[1]) + (t[2] + t[3]));
-        }
-        float a;
-        if constexpr (NB == 1) a = bs[0];
-        else if constexpr (NB == 2) a = bs[0] + bs[1];
-        else a = (bs[0] + bs[1]) + (bs[2] + bs[3]);
-        const float sm = fast_sm(table, a);
-        if constexpr (!NEG) {
-            const double coef = (1.0 - (double)sm) * c0;  // algorithms.cpp:867
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) Y[b][v] = (float)((double)xj[b][v] * coef + (double)Y[b][v]);
-        } else {
-            const float w = lr * sm;  // algorithms.cpp:907
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const float p = w * xj[b][v];
-                    Y[b][v] = Y[b][v] - p;
-                }
-        }
     }
+}
+
+template <int OPT, int LPI, int NB, bool NEG>
+__device__ __forceinline__ void pair_update_q(const float (&xi)[NB][4], const float4 (&xj4)[NB], float (&Y)[NB][4],
+                                              float lr, double c0, const float *table) {
+    pair_apply_q<OPT, LPI, NB, NEG>(xi, xj4, Y, lr, pair_coef_q<OPT, LPI, NB, NEG>(xi, xj4, lr, c0, table));
 }
 
 // Chained minibatches: row j is written by an earlier minibatch of this launch -- wait until it has been announced
@@ -823,10 +830,12 @@ __device__ __forceinline__ void qprocess(const StepArgs &a, const uint32_t *ids,
 // the list arrive in `j` (loaded a round ago), and once the list's last gathers have been issued the first U ids of the NEXT
 // round's list are requested into `j` -- behind the gathers, so that waiting for the rows does not wait for them.  A round
 // then costs one memory latency (the rows) instead of three dependent ones (item, ids, rows).
-template <int OPT, int LPI, int NB, int U, bool FULL>
+// `between` runs once per call, when the list's first gathers are out and before anything is waited for (all threads of the
+// workgroup reach it: it may hold a barrier; -> true: the workgroup gives up).
+template <int OPT, int LPI, int NB, int U, bool FULL, class Between>
 __device__ __forceinline__ void qprocess_pre(const StepArgs &a, const uint32_t *ids, uint32_t cnt, uint32_t maxcnt, uint32_t t, uint32_t D,
                                              const float (&xi)[NB][4], float (&Y)[NB][4], double c0, const float *table, bool &bad,
-                                             uint32_t (&j)[U], const uint32_t *next_ids, uint32_t next_cnt) {
+                                             uint32_t (&j)[U], const uint32_t *next_ids, uint32_t next_cnt, Between &&between) {
     uint32_t g = 0;
     do {
         float4 xj[U][NB];
@@ -879,11 +888,27 @@ __device__ __forceinline__ void qprocess_pre(const StepArgs &a, const uint32_t *
                 }
             }
         }
+        if (g == 0u && between()) {
+            bad = true;
+            return;
+        }
+        // the late rows' flags once more (in flight while the scalars of the rows that are here are computed: when a late row
+        // arrives, its own scalar and the additions in list order are all that is left of the item)
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (handed[u]) fl[u] = __hip_atomic_load(a.rowflag + j0[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        typename PairCoef<OPT, false>::type cf[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            cf[u] = 0;
+            if (g + u < cnt && !handed[u]) cf[u] = pair_coef_q<OPT, LPI, NB, false>(xi, xj[u], a.lr, c0, table);
+        }
         // the interactions in list order; a row that has not been announced yet is awaited just before its own
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (handed[u]) {
-                bad = wait_row(a, j0[u]) || bad;  // its flag, then agent-scope loads
+                if (fl[u] != a.seq) bad = wait_row(a, j0[u]) || bad;  // its flag, then agent-scope loads
+                asm volatile("" ::: "memory");
                 const float *src = a.Xn + (size_t)j0[u] * D + t * 4;
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
@@ -893,8 +918,9 @@ __device__ __forceinline__ void qprocess_pre(const StepArgs &a, const uint32_t *
 #endif
                     else xj[u][b] = load16_agent(src + 4 * LPI * b);
                 }
+                cf[u] = pair_coef_q<OPT, LPI, NB, false>(xi, xj[u], a.lr, c0, table);
             }
-            if (g + u < cnt) pair_update_q<OPT, LPI, NB, false>(xi, xj[u], Y, a.lr, c0, table);
+            if (g + u < cnt) pair_apply_q<OPT, LPI, NB, false>(xi, xj[u], Y, a.lr, cf[u]);
         }
         g += U;
     } while (g < maxcnt);
@@ -1213,7 +1239,10 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 constexpr uint32_t kWideJobsLds = 64;  // a workgroup's first jobs are staged in LDS when it starts (more stay in global memory)
 
-template <int OPT, int LPI, int NB, int U, bool FULL>
+// EARLY ("wide_samples_early"): the sample rows this launch writes itself are awaited BEFORE the first round's neighbour waits and the
+// samples' scalars are computed ahead of them; otherwise both stay behind the neighbours.  (Two kernels, not a run-time switch: with
+// both forms inlined the kernel grew enough to run 7 % slower on RMAT-20.)
+template <int OPT, int LPI, int NB, int U, bool FULL, bool EARLY>
 #ifndef F2V_WIDE_WAVES
 #define F2V_WIDE_WAVES 3
 #endif
@@ -1537,22 +1566,63 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (OPT == 5 ? F2V_WIDE_WAV
             const float degi = a.unit_degi ? 1.0f : (float)(1.0 / (double)(gdeg + 1u));  // algorithms.cpp:854
             c0 = (double)(a.lr * degi);
         }
-        bool bad = false;
+        bool bad = false, quit = false;
+        float cs[EARLY ? kLdsSamples : 1];  // EARLY: the samples' scalars (pair_coef_q), computed while the neighbours are still on their way
+        // (First round only) the sample rows this launch writes are awaited and staged.  EARLY -- where the minibatches of a launch
+        // are one dependency chain (a small graph) -- this happens behind the round's gathers and IN FRONT of its neighbour waits: a
+        // sample row and a neighbour row of the previous minibatch arrive at about the same time, and waiting for one after the other
+        // made every hop one flag + one row round trip longer (cora, D = 128: -6 %); where most workgroups wait for nothing (RMAT-20)
+        // the early barrier costs 2 %, and the staging stays behind the neighbours.
+        auto stage_late = [&]() -> bool {
+            if (late != 0u) {
+                if (stage_late_samples()) wg_bad = 1u;
+                late = 0u;
+                lds_barrier();
+                if (wg_bad) { quit = true; return true; }  // a sample row that never arrived: nobody stores
+            }
+            return false;
+        };
+        auto between = [&]() -> bool {
+            if constexpr (EARLY) {
+                if (stage_late()) return true;
+                if (lds_samples && !idle && last_chunk) {
+#pragma unroll
+                    for (int sidx = 0; sidx < (int)kLdsSamples; ++sidx) {
+                        cs[sidx] = 0.f;
+                        if ((uint32_t)sidx < a.ns) {
+                            float4 xs[NB];
+#pragma unroll
+                            for (int b = 0; b < NB; ++b) xs[b] = smp[sidx][LPI * b + t];
+                            cs[sidx] = pair_coef_q<OPT, LPI, NB, true>(xi, xs, a.lr, c0, table);
+                        }
+                    }
+                }
+            }
+            return false;
+        };
         qprocess_pre<OPT, LPI, NB, U, FULL>(a, a.nbr_ids + it.nb, cnt, wave_max_of_items<LPI>(cnt), t, D, xi, Y, c0, table, bad, jpre,
-                                            a.nbr_ids + itn.nb, (itn.flags & kItemIdle) ? 0u : itn.cnt);
-        if (late != 0u) {  // (first round only) the sample rows this launch writes: awaited now, behind the round's gathers
-            if (stage_late_samples()) wg_bad = 1u;
-            late = 0u;
-            lds_barrier();
-            if (wg_bad) return;  // a sample row that never arrived: nobody stores
-        }
+                                            a.nbr_ids + itn.nb, (itn.flags & kItemIdle) ? 0u : itn.cnt, between);
+        if constexpr (!EARLY) (void)stage_late();
+        if (quit) return;
         if (lds_samples) {
             if (!idle && last_chunk) {
-                for (uint32_t sidx = 0; sidx < a.ns; ++sidx) {
-                    float4 xs[NB];
+                if constexpr (EARLY) {
 #pragma unroll
-                    for (int b = 0; b < NB; ++b) xs[b] = smp[sidx][LPI * b + t];
-                    pair_update_q<OPT, LPI, NB, true>(xi, xs, Y, a.lr, c0, table);
+                    for (int sidx = 0; sidx < (int)kLdsSamples; ++sidx) {
+                        if ((uint32_t)sidx < a.ns) {
+                            float4 xs[NB];
+#pragma unroll
+                            for (int b = 0; b < NB; ++b) xs[b] = smp[sidx][LPI * b + t];
+                            pair_apply_q<OPT, LPI, NB, true>(xi, xs, Y, a.lr, cs[sidx]);
+                        }
+                    }
+                } else {
+                    for (uint32_t sidx = 0; sidx < a.ns; ++sidx) {
+                        float4 xs[NB];
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) xs[b] = smp[sidx][LPI * b + t];
+                        pair_update_q<OPT, LPI, NB, true>(xi, xs, Y, a.lr, c0, table);
+                    }
                 }
             }
         } else {

@@ -416,14 +416,16 @@ def test_chained_minibatches_equal_one_launch_per_minibatch(F, option, dim, batc
 @pytest.mark.parametrize("option,dim,chunk,fanin,tune", [
     (5, 128, 4, 32, {}), (5, 128, 2, 32, {"wide_span": 1, "wide_finish": 1}), (6, 128, 4, 4, {"wide_phases": 3}), (5, 64, 8, 2, {"wide_finish": 2, "wide_span": 4}),
     (6, 32, 3, 32, {"wide_phases": 2, "wide_rows": 4096}), (5, 256, 4, 8, {"wide_finish": 8}), (5, 16, 4, 32, {}), (5, 128, 4, 32, {"wide_order": 2, "wide_rounds": 2}),
-    (5, 16, 4, 32, {"wide_min_width": 16}), (6, 16, 4, 32, {"wide_min_width": 64}), (5, 32, 4, 4, {"wide_min_width": 128}), (6, 48, 4, 32, {"wide_min_width": 32})])
+    (5, 16, 4, 32, {"wide_min_width": 16}), (6, 16, 4, 32, {"wide_min_width": 64}), (5, 32, 4, 4, {"wide_min_width": 128}), (6, 48, 4, 32, {"wide_min_width": 32}),
+    (5, 128, 4, 32, {"wide_samples_early": 0}), (6, 64, 4, 32, {"wide_samples_early": 1, "wide_rounds": 2})])
 def test_wide_form_equals_the_other_launch_forms(F, option, dim, chunk, fanin, tune):
     """The three ways f2v_train can launch small minibatches -- one launch each; chained with partial sums through HBM and
     combine-tree nodes (round 2); chained in the wide form (round 3: a row's pieces meet in LDS, finisher + helper workgroups,
     tree nodes only above fanin^2 pieces) -- add the same numbers in the same order: identical bits, for every fan-in, chunk
     and split of a row between finisher and helpers (RMAT scale 14: hubs of thousands of neighbours, i.e. rows of one group,
     of several, and of more than fanin^2 pieces), and identical to the oracle.  "wide_min_width": narrow rows on a wider sub-wave
-    layout (fewer items per wavefront; part of every lane group idle) -- the wider tree's zero padding changes no bit."""
+    layout (fewer items per wavefront; part of every lane group idle) -- the wider tree's zero padding changes no bit.
+    "wide_samples_early": when the sample rows a launch writes itself are awaited (a small graph's default is 1)."""
     _need_round_robin_dispatch(F)
     from force2vec_amd.graph import rmat_csr
     rowptr, colids = rmat_csr(14, 16, seed=4)
