@@ -181,7 +181,7 @@ def verify_rows(F, eng, rowptr, colids, args, n_rows=32):
     return int(len(rows))
 
 
-def kernel_name(args, pushing, form, wide_width=0):
+def kernel_name(args, pushing, form, wide_width=0, wide_early=0):
     """The step kernel the last f2v_train of this shape launched: `form` is the engine's own answer ("last_train_form": 0 one
     launch per minibatch, 1 chained, 2 chained in the wide form) -- the launch rules live in f2v_engine.hip, not here."""
     if args.dim % 4 or args.dim > 256:
@@ -193,7 +193,7 @@ def kernel_name(args, pushing, form, wide_width=0):
         w = max(w, wide_width)  # the wide form may run narrow rows on a wider layout ("wide_min_width")
     opt, lpi, nb, u, full = 5 if args.option in (5, 8, 11) else 6, min(16, w // 4), max(1, w // 64), 4 if w >= 128 else 8, "true" if w == args.dim else "false"
     if form == 2 and not pushing:
-        return "f2v::qwide_chain_kernel<%d, %d, %d, %d, %s>" % (opt, lpi, nb, u, full)
+        return "f2v::qwide_chain_kernel<%d, %d, %d, %d, %s, %s>" % (opt, lpi, nb, u, full, "true" if wide_early else "false")
     if form == 1 and not pushing:
         return "f2v::qstep_chain_kernel<%d, %d, %d, %d, %s>" % (opt, lpi, nb, u, full)
     return "f2v::qstep_kernel<%d, %d, %d, %d, %s, %s>" % (opt, lpi, nb, u, "true" if pushing else "false", full)
@@ -566,6 +566,7 @@ def main():
     main_settle = state["settle_epochs"]
     main_form = eng.get_param("last_train_form")
     main_wide_width = eng.get_param("last_wide_width") if main_form == 2 else 0
+    main_wide_early = eng.get_param("last_wide_early") if main_form == 2 else 0
     note(rank, "timed region done: %.3f ms per epoch" % (dt / args.steps * 1e3))
     # rForce2Vec attracts along 5 walk samples per vertex, not along the CSR's nonzeros
     units = 5 * n if args.option in (7, 10) else nnz
@@ -602,7 +603,7 @@ def main():
         t_launch = (st["device_seconds"] if st["device_seconds"] else dt) / launches
         comp = st["compulsory_bytes"] / launches
         alg = st["algorithmic_bytes"] / launches
-        kname = kernel_name(args, use_dist and world > 1 and state["exchange"] == "push" and eng.get_param("push_fused"), main_form, main_wide_width)
+        kname = kernel_name(args, use_dist and world > 1 and state["exchange"] == "push" and eng.get_param("push_fused"), main_form, main_wide_width, main_wide_early)
         ach = comp / t_launch * 1e-9
         roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                 "kernel": kname, "compulsory_bytes": comp, "compulsory_bytes_per_launch": comp, "avg_launch_us": t_launch * 1e6, "launches": st["step_launches"],

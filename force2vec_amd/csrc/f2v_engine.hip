@@ -115,6 +115,7 @@ struct f2v_ctx {
     uint32_t mark_every = 0;       // "epoch_marks"
     std::vector<double> marks;     // f2v_train_marks
     uint32_t last_wide_width = 0;  // the layout width of the last wide-form f2v_train ("last_wide_width")
+    bool last_wide_early = false;  // ... and whether it ran the kernel's EARLY form ("last_wide_early")
     int last_train_form = 0;  // how the last f2v_train launched: 0 one launch per minibatch, 1 chained, 2 chained in the wide form ("last_train_form")
     bool plan_overflow = false;  // a launch plan needed more than 2^28 partial-sum slots (kItemSlotMask)
     uint32_t *h_kerr = nullptr;  // pinned: the kernel error words as of the last completed epoch-end copy (train_impl)
@@ -1437,6 +1438,7 @@ int launch_wide(f2v_ctx *c, int math, const WidePlan &plan, const uint32_t *d_id
     const int o = (math == 5) ? 5 : 6;
     // "wide_samples_early" (-1 = automatic): on for graphs of up to 2 M nonzeros, whose launches are one dependency chain
     const bool early = c->wide_samples_early >= 0 ? c->wide_samples_early != 0 : c->nnz <= (2ull << 20);
+    c->last_wide_early = early;
 #define F2V_W3(OPT, LPI, NB, U, FULL, EARLY) hipLaunchKernelGGL((qwide_chain_kernel<OPT, LPI, NB, U, FULL, EARLY>), dim3(plan.n_wgs), dim3(256), 0, c->stream, wa)
 #define F2V_W2(OPT, LPI, NB, U, FULL) do { if (early) F2V_W3(OPT, LPI, NB, U, FULL, true); else F2V_W3(OPT, LPI, NB, U, FULL, false); } while (0)
 #define F2V_W(OPT, LPI, NB, U) do { if (full) F2V_W2(OPT, LPI, NB, U, true); else F2V_W2(OPT, LPI, NB, U, false); } while (0)
@@ -2093,6 +2095,7 @@ int f2v_get_param(f2v_handle c, const char *name, int64_t *out) {
     if (!strcmp(name, "wide_finish")) { *out = c->wide_finish; return F2V_OK; }
     if (!strcmp(name, "last_train_form")) { *out = c->last_train_form; return F2V_OK; }
     if (!strcmp(name, "last_wide_width")) { *out = c->last_wide_width; return F2V_OK; }
+    if (!strcmp(name, "last_wide_early")) { *out = c->last_wide_early ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "recover")) { *out = c->recover ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "recoveries")) { *out = c->recoveries; return F2V_OK; }
     if (!strcmp(name, "chain_max_batch")) { *out = c->chain_max_batch; return F2V_OK; }

@@ -79,7 +79,7 @@ int f2v_get_embeddings(f2v_handle h, float *x_out);
  * workgroups go: measured neutral), "wide_min_width" (0 = automatic) shape its
  * workgroup programs; "wide_samples_early" (-1 = automatic: small graphs): the sample rows a launch itself writes are awaited before
  * the first neighbour waits instead of after them (placement in time only); "last_train_form" answers how the last f2v_train launched (0 one launch per minibatch, 1 chained, 2 wide), "last_wide_width"
- * the sub-wave layout a wide run used; "class_cut" (default 1): a split row's pieces also end where its ascending neighbour ids cross
+ * the sub-wave layout a wide run used, "last_wide_early" whether it ran the kernel's EARLY form; "class_cut" (default 1): a split row's pieces also end where its ascending neighbour ids cross
  * from one eighth of the id range into the next (part of the summation order, restated by the oracle; it is what makes
  * "piece_affinity" pure); "piece_affinity" (default 1): a split row's pieces run on the XCD that owns
  * the id range of their neighbours, so that each of the eight L2s caches its own eighth of the matrix (placement only:
