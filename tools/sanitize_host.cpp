@@ -20,6 +20,14 @@ int main(int argc, char **argv) {
         }
         std::vector<float> x((size_t)n * 16);
         f2v_rng *g = f2v_rng_create(1); f2v_rng_fill(g, x.data(), x.size(), 0); f2v_rng_jump(g, 12345); f2v_rng_destroy(g);
+        {   // option 7's walks, two epochs from one stream (blocks of predicted stream positions, draws given back)
+            std::vector<uint32_t> w((size_t)n * 5);
+            f2v_rng *gw = f2v_rng_create(1);
+            for (int e = 0; e < 2; e++)
+                if (f2v_rng_walks(gw, rp, ci, n, nnz, w.data())) { printf("walks failed %s\n", f2v_last_error()); return 1; }
+            for (uint32_t v : w) if (v >= n) { printf("walk sample outside the graph\n"); return 1; }
+            f2v_rng_destroy(gw);
+        }
         char name[512]; f2v_output_name(argv[a], "/tmp/asan/", 5, 0, 256, 16, 3, 5, name, sizeof name);
         if (f2v_write_embd(name, x.data(), n, 16)) return 1;
         if (f2v_write_csr_bin("/tmp/asan/g.f2vcsr", rp, ci, n, nnz)) return 1;

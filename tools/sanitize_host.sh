@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
 # AddressSanitizer + UBSan over the host side of libf2v (CPU only: GPU ASan is not available on this pool):
-# MatrixMarket reader (threaded), binary CSR, .embd writer, rand() jump-ahead fill, push masks / shard bounds (threaded).
+# MatrixMarket reader (threaded), binary CSR, .embd writer, rand() jump-ahead fill, option 7's walk generation, push masks / shard bounds (threaded).
 #   tools/sanitize_host.sh /abs/path/graph.mtx [more.mtx ...]      (scratch files go to /tmp/asan)
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
