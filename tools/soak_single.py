@@ -10,5 +10,14 @@ for option in (5, 6):
     for batch, epochs in ((65536, 1500), (16384, 600), (4096, 500), (1024, 300), (384, 250), (256, 250)):
         t0 = time.time()
         dev = eng.train(option, epochs, batch)
-        print("option %d batch %d: %d epochs, %d launches, device %.2fs (%.3f ms/epoch), no give-ups" % (option, batch, epochs, eng.stats()["step_launches"], dev, dev / epochs * 1e3), flush=True)
+        print("option %d batch %d: %d epochs, %d launches, device %.2fs (%.3f ms/epoch), no give-ups (recoveries %d)" % (option, batch, epochs, eng.stats()["step_launches"], dev, dev / epochs * 1e3, eng.get_param("recoveries")), flush=True)
+    eng.close()
+# small graph (the kernel's EARLY form: a launch is one dependency chain)
+import os
+rp, ci = F.read_mtx(os.path.join("tests", "golden", "cora.mtx"))
+for option, dim in ((5, 16), (5, 128), (6, 128), (7, 64)):
+    eng = F.Engine(rp, ci, dim)
+    eng.srand(1); eng.init_embeddings(0 if option == 5 else 1)
+    dev = eng.train(option, 20000, 256)
+    print("cora option %d D=%d batch 256: 20000 epochs, device %.2fs, form %d, recoveries %d" % (option, dim, dev, eng.get_param("last_train_form"), eng.get_param("recoveries")), flush=True)
     eng.close()
