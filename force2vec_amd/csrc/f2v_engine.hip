@@ -153,6 +153,13 @@ struct f2v_ctx {
     uint32_t wide_order = 0;    // workgroups of a minibatch: 0 helpers, finishers, packed rows; 1 helpers, packed, finishers; 2 packed, helpers, finishers
     uint32_t wide_phases = 1;   // phases (of 32 piece slots) a workgroup of small rows runs
     uint32_t wide_min_width = 0;   // "wide_min_width" (wide_width; 0: chosen from the graph and the batch)
+    // "wide_epochs": up to this many EPOCHS of a small graph in one wide-form launch (WideArgs::wgs_per_epoch): ring of matrices, per-epoch
+    // row flags / partial-sum slots / their flags; 0 = automatic (32 for graphs of up to 2 M nonzeros that fit one launch, else 1)
+    uint32_t wide_epochs = 0, last_wide_epochs = 1;
+    float *d_ring = nullptr, *d_ring_partials = nullptr;
+    uint32_t *d_ring_flags = nullptr, *d_ring_ready = nullptr;
+    uint32_t ring_epochs = 0;   // epochs the ring buffers are sized for
+    size_t ring_slots = 0;      // partial-sum slots per epoch they are sized for
     int wide_samples_early = -1;  // "wide_samples_early": StepArgs::samples_early; -1 = automatic (graphs of up to 2 M nonzeros: the launch is one dependency chain)
     uint32_t wide_rounds = 0;   // rounds per phase of such a workgroup (0: one for minibatches of up to 512 rows, else as many as fill the piece slots)
     uint32_t wide_span = 2;     // fan-in groups per helper workgroup
@@ -1393,18 +1400,46 @@ int launch_chain(f2v_ctx *c, int math, const ChainPlan &plan, const uint32_t *d_
 
 
 // One launch of the wide form (qwide_chain_kernel): minibatches [plan.first_batch, +plan.n_batches)
-int launch_wide(f2v_ctx *c, int math, const WidePlan &plan, const uint32_t *d_ids_epoch, uint32_t ids_stride, uint32_t ns, float lr, int bs_mode) {
+// `epochs` > 1 (the plan covers the whole graph): that many epochs chained in the one launch -- the current matrix is copied into a ring
+// of epochs + 1 matrices, epoch e reads matrix e and writes matrix e + 1 behind its own row flags, and the last one is copied back
+// (two 1-MB copies per launch on a graph like cora, where the launch boundary they replace is a third of an epoch).
+int launch_wide(f2v_ctx *c, int math, const WidePlan &plan, const uint32_t *d_ids_epoch, uint32_t ids_stride, uint32_t ns, float lr, int bs_mode,
+                uint32_t epochs = 1, uint64_t ids_epoch_stride = 0) {
     int rc;
-    if (c->upd_hi != c->upd_lo && plan.lo != c->upd_hi) {
+    const bool ring = epochs > 1;
+    if (ring || (c->upd_hi != c->upd_lo && plan.lo != c->upd_hi)) {
         if ((rc = flush_pending(c)) != F2V_OK) return rc;
+    }
+    const size_t matrix = (size_t)c->n * c->D;
+    if (ring) {
+        if (plan.lo != 0 || plan.hi != c->n || plan.n_node_wgs != 0) return fail(F2V_ESTATE, "launch_wide: epochs can only be chained where one launch covers the graph");
+        if (c->ring_epochs < epochs || c->ring_slots < std::max<size_t>(plan.n_slots, 1)) {
+            HIPC(hipStreamSynchronize(c->stream));
+            for (void *p : {(void *)c->d_ring, (void *)c->d_ring_partials, (void *)c->d_ring_flags, (void *)c->d_ring_ready})
+                if (p) (void)hipFree(p);
+            c->d_ring = c->d_ring_partials = nullptr;
+            c->d_ring_flags = c->d_ring_ready = nullptr;
+            const uint32_t cap = std::max(epochs, c->ring_epochs);
+            const size_t slots = std::max<size_t>(std::max<size_t>(plan.n_slots, c->ring_slots), 1);
+            c->ring_epochs = 0;
+            HIPC(hipMalloc((void **)&c->d_ring, (size_t)(cap + 1) * matrix * sizeof(float)));
+            HIPC(hipMalloc((void **)&c->d_ring_partials, (size_t)cap * slots * c->D * sizeof(float)));
+            HIPC(hipMalloc((void **)&c->d_ring_flags, (size_t)cap * c->n * sizeof(uint32_t)));
+            HIPC(hipMalloc((void **)&c->d_ring_ready, (size_t)cap * slots * sizeof(uint32_t)));
+            HIPC(hipMemsetAsync(c->d_ring_flags, 0, (size_t)cap * c->n * sizeof(uint32_t), c->stream));  // 0 is no launch's sequence number
+            HIPC(hipMemsetAsync(c->d_ring_ready, 0, (size_t)cap * slots * sizeof(uint32_t), c->stream));
+            c->ring_epochs = cap;
+            c->ring_slots = slots;
+        }
+        HIPC(hipMemcpyAsync(c->d_ring, c->d_X[c->cur], matrix * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     }
     WideArgs wa{};
     StepArgs &a = wa.base;
-    a.X = c->d_X[c->cur];
-    a.Xn = c->d_X[c->cur ^ 1];
+    a.X = ring ? c->d_ring : c->d_X[c->cur];
+    a.Xn = ring ? c->d_ring + matrix : c->d_X[c->cur ^ 1];
     a.rowptr = c->d_rowptr;
     a.nbr_ids = math == 7 ? c->d_walks : c->d_colids;
-    a.partials = c->d_partials;
+    a.partials = ring ? c->d_ring_partials : c->d_partials;
     a.items = c->d_items + plan.item_off;
     a.sm_table = c->d_table;
     a.D = c->D;
@@ -1414,7 +1449,7 @@ int launch_wide(f2v_ctx *c, int math, const WidePlan &plan, const uint32_t *d_id
     a.unit_degi = c->unit_degi ? 1u : 0u;
     a.lr = lr;
     a.fin_items = c->d_hubs + plan.fin_off;
-    a.ready = c->d_ready;
+    a.ready = ring ? c->d_ring_ready : c->d_ready;
     a.err = c->d_kerr;
     a.timeout_ticks = (unsigned long long)std::min(c->tree_timeout_ms, c->chain_timeout_ms) * 100000ull;
     a.seq = ++c->launch_seq;
@@ -1423,8 +1458,15 @@ int launch_wide(f2v_ctx *c, int math, const WidePlan &plan, const uint32_t *d_id
     a.test_withhold_slot = c->test_withhold_slot;
     a.test_withhold_row = c->test_withhold_row;
 #endif
-    a.rowflag = c->d_rowflag;
+    a.rowflag = ring ? c->d_ring_flags : c->d_rowflag;
     a.chain_lo = plan.lo;
+    if (ring) {
+        wa.wgs_per_epoch = plan.n_wgs;
+        wa.n_rows = c->n;
+        wa.slots_per_epoch = (uint32_t)c->ring_slots;
+        wa.ring_stride = matrix;
+        wa.ids_epoch_stride = ids_epoch_stride;
+    }
 #ifdef F2V_TEST_HOOKS
     a.test_nowait = c->test_chain_mode;
     a.stamps = c->d_stamps;
@@ -1437,10 +1479,12 @@ int launch_wide(f2v_ctx *c, int math, const WidePlan &plan, const uint32_t *d_id
     const bool full = width == c->D;
     const int o = (math == 5) ? 5 : 6;
     // "wide_samples_early" (-1 = automatic): on for graphs of up to 2 M nonzeros, whose launches are one dependency chain
-    const bool early = c->wide_samples_early >= 0 ? c->wide_samples_early != 0 : c->nnz <= (2ull << 20);
+    const bool early = ring || (c->wide_samples_early >= 0 ? c->wide_samples_early != 0 : c->nnz <= (2ull << 20));
     c->last_wide_early = early;
-#define F2V_W3(OPT, LPI, NB, U, FULL, EARLY) hipLaunchKernelGGL((qwide_chain_kernel<OPT, LPI, NB, U, FULL, EARLY>), dim3(plan.n_wgs), dim3(256), 0, c->stream, wa)
-#define F2V_W2(OPT, LPI, NB, U, FULL) do { if (early) F2V_W3(OPT, LPI, NB, U, FULL, true); else F2V_W3(OPT, LPI, NB, U, FULL, false); } while (0)
+    c->last_wide_epochs = std::max(c->last_wide_epochs, epochs);  // (the most epochs one launch of this f2v_train has carried)
+    const uint32_t grid = plan.n_wgs * epochs;
+#define F2V_W3(OPT, LPI, NB, U, FULL, MODE) hipLaunchKernelGGL((qwide_chain_kernel<OPT, LPI, NB, U, FULL, MODE>), dim3(grid), dim3(256), 0, c->stream, wa)
+#define F2V_W2(OPT, LPI, NB, U, FULL) do { if (ring) F2V_W3(OPT, LPI, NB, U, FULL, 2); else if (early) F2V_W3(OPT, LPI, NB, U, FULL, 1); else F2V_W3(OPT, LPI, NB, U, FULL, 0); } while (0)
 #define F2V_W(OPT, LPI, NB, U) do { if (full) F2V_W2(OPT, LPI, NB, U, true); else F2V_W2(OPT, LPI, NB, U, false); } while (0)
     switch (width) {
         case 16: if (o == 5) F2V_W(5, 4, 1, 8); else F2V_W(6, 4, 1, 8); break;
@@ -1453,18 +1497,22 @@ int launch_wide(f2v_ctx *c, int math, const WidePlan &plan, const uint32_t *d_id
 #undef F2V_W2
 #undef F2V_W3
     HIPC(hipGetLastError());
-    if (c->upd_hi == c->upd_lo) c->upd_lo = plan.lo;
-    c->upd_hi = plan.hi;
-    c->pending = true;
-    c->p_lo = plan.last_lo;
-    c->p_hi = plan.hi;
-    c->stats.hub_rows += plan.n_hubs;
-    c->stats.hub_chunks += plan.n_chunks;
+    if (ring) {  // the last epoch's matrix becomes the current one: nothing is pending
+        HIPC(hipMemcpyAsync(c->d_X[c->cur], c->d_ring + (size_t)epochs * matrix, matrix * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        if (c->upd_hi == c->upd_lo) c->upd_lo = plan.lo;
+        c->upd_hi = plan.hi;
+        c->pending = true;
+        c->p_lo = plan.last_lo;
+        c->p_hi = plan.hi;
+    }
+    c->stats.hub_rows += (uint64_t)plan.n_hubs * epochs;
+    c->stats.hub_chunks += (uint64_t)plan.n_chunks * epochs;
     c->stats.step_launches += 1;
-    c->stats.rows += plan.hi - plan.lo;
-    c->stats.nnz += plan.nnz;
-    c->stats.algorithmic_bytes += plan.nnz * (4ull * c->D + 4) + (uint64_t)(plan.hi - plan.lo) * (8ull * c->D + 4) + (uint64_t)plan.n_batches * ns * (4ull * c->D + 4);
-    c->stats.compulsory_bytes += plan.compulsory;
+    c->stats.rows += (uint64_t)(plan.hi - plan.lo) * epochs;
+    c->stats.nnz += plan.nnz * epochs;
+    c->stats.algorithmic_bytes += (plan.nnz * (4ull * c->D + 4) + (uint64_t)(plan.hi - plan.lo) * (8ull * c->D + 4) + (uint64_t)plan.n_batches * ns * (4ull * c->D + 4)) * epochs;
+    c->stats.compulsory_bytes += plan.compulsory * epochs;
     return F2V_OK;
 }
 
@@ -1741,7 +1789,7 @@ int f2v_destroy(f2v_handle c) {
     (void)hipSetDevice(c->device);
     (void)push_detach(c);
     void *ptrs[] = {c->d_rowptr, c->d_colids, c->d_walks, c->d_walks_alt, c->d_ids, c->d_X[0], c->d_X[1],
-                    c->d_partials, c->d_table, c->d_items, c->d_hubs, c->d_ready, c->d_kerr, c->d_wg, c->d_rowflag, c->d_snap, c->d_wide, c->d_jobs, c->push.flags, c->push.d_err, c->push.d_masks, c->push.d_patch, c->push.landing_buf};
+                    c->d_partials, c->d_table, c->d_items, c->d_hubs, c->d_ready, c->d_kerr, c->d_wg, c->d_rowflag, c->d_snap, c->d_wide, c->d_jobs, c->d_ring, c->d_ring_partials, c->d_ring_flags, c->d_ring_ready, c->push.flags, c->push.d_err, c->push.d_masks, c->push.d_patch, c->push.landing_buf};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 #ifdef F2V_TEST_HOOKS
@@ -1963,6 +2011,11 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
         c->chain_max_batch = (uint32_t)value;
         return F2V_OK;
     }
+    if (!strcmp(name, "wide_epochs")) {
+        if (value < 0 || value > 1024) return fail(F2V_EINVAL, "wide_epochs must be 0 (automatic) ... 1024");
+        c->wide_epochs = (uint32_t)value;
+        return F2V_OK;
+    }
     if (!strcmp(name, "wide_samples_early")) {
         if (value < -1 || value > 1) return fail(F2V_EINVAL, "wide_samples_early must be -1 (automatic), 0 or 1");
         c->wide_samples_early = (int)value;
@@ -2088,6 +2141,8 @@ int f2v_get_param(f2v_handle c, const char *name, int64_t *out) {
     if (!strcmp(name, "wide_max_batch")) { *out = c->wide_max_batch; return F2V_OK; }
     if (!strcmp(name, "wide_min_width")) { *out = c->wide_min_width; return F2V_OK; }
     if (!strcmp(name, "wide_samples_early")) { *out = c->wide_samples_early; return F2V_OK; }
+    if (!strcmp(name, "wide_epochs")) { *out = c->wide_epochs; return F2V_OK; }
+    if (!strcmp(name, "last_wide_epochs")) { *out = c->last_wide_epochs; return F2V_OK; }
     if (!strcmp(name, "wide_rows")) { *out = c->wide_rows; return F2V_OK; }
     if (!strcmp(name, "wide_span")) { *out = c->wide_span; return F2V_OK; }
     if (!strcmp(name, "wide_order")) { *out = c->wide_order; return F2V_OK; }
@@ -2400,6 +2455,16 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
     const bool chained = iters > 0 && chain_usable(c, math, batch, bs_mode, sharded);
     const bool wide = chained && wide_usable(c) && batch <= c->wide_max_batch && chain_len(c, batch, true) >= 2;
     const uint32_t K = chained ? chain_len(c, batch, wide) : 1;
+    uint32_t epochs_max = 1;  // "wide_epochs"
+    if (wide && all_upfront && math != 7 && !bs_mode && ns <= 8 && !c->mark_every
+#ifdef F2V_TEST_HOOKS
+        && !c->d_stamps && !c->test_chain_mode
+#endif
+    ) {
+        epochs_max = c->wide_epochs ? c->wide_epochs : (c->nnz <= (2ull << 20) ? 32u : 1u);
+        epochs_max = (uint32_t)std::min<uint64_t>(epochs_max, (8ull << 30) / std::max<uint64_t>((uint64_t)n * c->D * sizeof(float), 1));  // the ring stays below 8 GiB
+    }
+    c->last_wide_epochs = 1;
     c->last_train_form = wide ? 2 : chained ? 1 : 0;
     if (wide) c->last_wide_width = wide_width(c, batch);
     if (wide) {
@@ -2640,7 +2705,11 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
             for (uint32_t b0 = 0; b0 < nb; b0 += K) {
                 const WidePlan plan = wide_plan_for(c, b0, std::min(K, nb - b0), batch, math == 7);
                 if ((rc = upload_plans(c)) != F2V_OK) return rc;
-                if ((rc = launch_wide(c, math, plan, d_epoch_ids, (uint32_t)stride, ns, lr, bs_mode)) != F2V_OK) return rc;
+                // epochs chained in one launch: the plan covers the graph, every epoch's sample ids are on the device, no walks, no marks
+                uint32_t E = 1;
+                if (epochs_max > 1 && K >= nb && plan.n_node_wgs == 0) E = std::min(epochs_max, iters - it);
+                if ((rc = launch_wide(c, math, plan, d_epoch_ids, (uint32_t)stride, ns, lr, bs_mode, E, per_epoch)) != F2V_OK) return rc;
+                it += E - 1;
             }
         } else if (chained) {
             for (uint32_t b0 = 0; b0 < nb; b0 += K) {

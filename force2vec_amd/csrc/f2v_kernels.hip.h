@@ -740,8 +740,8 @@ __device__ __forceinline__ void pair_update_q(const float (&xi)[NB][4], const fl
 // the launch is lost already); the caller then stores nothing.
 // (forceinline on purpose: as a real call -- __noinline__, to keep the cold path out of the loop -- it made the whole chained
 // kernel 3x slower: 12.4 instead of 4.7 ms per epoch without a single wait taken, tools/chain_probe_variants.py)
-__device__ __forceinline__ bool wait_row_slow(const StepArgs &a, uint32_t j) {
-    const uint32_t *f = a.rowflag + j;
+__device__ __forceinline__ bool wait_row_slow(const StepArgs &a, const uint32_t *flags, uint32_t j) {
+    const uint32_t *f = flags + j;
     const unsigned long long t0 = wall_clock64();
     for (uint32_t spins = 1;; ++spins) {
         __builtin_amdgcn_s_sleep(1);
@@ -764,12 +764,14 @@ __device__ __forceinline__ bool wait_row_slow(const StepArgs &a, uint32_t j) {
     }
 }
 
-__device__ __forceinline__ bool wait_row(const StepArgs &a, uint32_t j) {
+// (`flags`: the array the row's writer announces in -- the launch's own, or, where a launch chains several epochs, an earlier epoch's)
+__device__ __forceinline__ bool wait_row_at(const StepArgs &a, const uint32_t *flags, uint32_t j) {
     bool bad = false;
-    if (__hip_atomic_load(a.rowflag + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.seq) bad = wait_row_slow(a, j);
+    if (__hip_atomic_load(flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.seq) bad = wait_row_slow(a, flags, j);
     asm volatile("" ::: "memory");  // the row's loads stay behind the poll
     return bad;
 }
+__device__ __forceinline__ bool wait_row(const StepArgs &a, uint32_t j) { return wait_row_at(a, a.rowflag, j); }
 
 __device__ __forceinline__ const float *row_src(const StepArgs &a, uint32_t j, uint32_t D) {
     return ((j - a.upd_lo) < a.upd_rows ? a.Xn : a.X) + (size_t)j * D;
@@ -835,18 +837,22 @@ __device__ __forceinline__ void qprocess(const StepArgs &a, const uint32_t *ids,
 template <int OPT, int LPI, int NB, int U, bool FULL, class Between>
 __device__ __forceinline__ void qprocess_pre(const StepArgs &a, const uint32_t *ids, uint32_t cnt, uint32_t maxcnt, uint32_t t, uint32_t D,
                                              const float (&xi)[NB][4], float (&Y)[NB][4], double c0, const float *table, bool &bad,
-                                             uint32_t (&j)[U], const uint32_t *next_ids, uint32_t next_cnt, Between &&between) {
+                                             uint32_t (&j)[U], const uint32_t *next_ids, uint32_t next_cnt, Between &&between,
+                                             const uint32_t *prev_flags) {
+    // prev_flags (a launch that chains epochs, from its second epoch on): the rows this epoch has not updated yet were written by
+    // the launch's PREVIOUS epoch -- they are awaited too, in that epoch's flag array, and read from the first matrix at agent scope
     uint32_t g = 0;
     do {
         float4 xj[U][NB];
-        bool handed[U];
+        bool handed[U], inr[U];
         uint32_t fl[U];
         // rows written inside this launch: ALL their flags are requested first (side by side, behind nothing) ...
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            handed[u] = (g + u < cnt) && (j[u] - a.chain_lo) < a.chain_rows;
+            inr[u] = (j[u] - a.chain_lo) < a.chain_rows;
+            handed[u] = (g + u < cnt) && (inr[u] || prev_flags != nullptr);
             fl[u] = 0u;
-            if (handed[u]) fl[u] = __hip_atomic_load(a.rowflag + j[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (handed[u]) fl[u] = __hip_atomic_load((inr[u] ? a.rowflag : prev_flags) + j[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // ... then the rows that need no wait ...
 #pragma unroll
@@ -875,7 +881,7 @@ __device__ __forceinline__ void qprocess_pre(const StepArgs &a, const uint32_t *
             for (int u = 0; u < U; ++u) {
                 if (handed[u] && fl[u] == a.seq) {
                     asm volatile("" ::: "memory");  // the row's loads stay behind the poll
-                    const float *src = a.Xn + (size_t)j0[u] * D + t * 4;
+                    const float *src = (inr[u] ? a.Xn : a.X) + (size_t)j0[u] * D + t * 4;
 #pragma unroll
                     for (int b = 0; b < NB; ++b) {
                         if (!(FULL || 4u * LPI * b + 4u * t < D)) xj[u][b] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -896,7 +902,24 @@ __device__ __forceinline__ void qprocess_pre(const StepArgs &a, const uint32_t *
         // arrives, its own scalar and the additions in list order are all that is left of the item)
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (handed[u]) fl[u] = __hip_atomic_load(a.rowflag + j0[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (handed[u]) fl[u] = __hip_atomic_load((inr[u] ? a.rowflag : prev_flags) + j0[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev_flags != nullptr) {
+            // (a launch that chains epochs: EVERY row is behind a flag, and when a workgroup starts -- epochs ahead of its turn -- none
+            // is up; the rows whose flags this second look finds up are requested side by side, not one by one in the loop below)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (handed[u] && fl[u] == a.seq) {
+                    asm volatile("" ::: "memory");
+                    const float *src = (inr[u] ? a.Xn : a.X) + (size_t)j0[u] * D + t * 4;
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        if (!(FULL || 4u * LPI * b + 4u * t < D)) xj[u][b] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        else xj[u][b] = load16_agent(src + 4 * LPI * b);
+                    }
+                    handed[u] = false;
+                }
+            }
+        }
         typename PairCoef<OPT, false>::type cf[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -907,9 +930,9 @@ __device__ __forceinline__ void qprocess_pre(const StepArgs &a, const uint32_t *
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (handed[u]) {
-                if (fl[u] != a.seq) bad = wait_row(a, j0[u]) || bad;  // its flag, then agent-scope loads
+                if (fl[u] != a.seq) bad = wait_row_at(a, inr[u] ? a.rowflag : prev_flags, j0[u]) || bad;  // its flag, then agent-scope loads
                 asm volatile("" ::: "memory");
-                const float *src = a.Xn + (size_t)j0[u] * D + t * 4;
+                const float *src = (inr[u] ? a.Xn : a.X) + (size_t)j0[u] * D + t * 4;
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
                     if (!(FULL || 4u * LPI * b + 4u * t < D)) xj[u][b] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1230,7 +1253,14 @@ struct WideArgs {
     const WideDesc *wg;
     const WJob *jobs;
     const uint32_t *ids;      // the epoch's sample ids, `ids_stride` per minibatch
-    uint32_t ids_stride;
+    uint32_t ids_stride;    // Several EPOCHS in one launch ("wide_epochs"; wgs_per_epoch = 0: one epoch, the fields below unused): workgroup b belongs to
+    // epoch e = b / wgs_per_epoch of the launch and runs the program of workgroup b % wgs_per_epoch.  base.X is a ring of
+    // matrices `ring_stride` floats apart: epoch e reads matrix e and writes matrix e + 1 (no buffer is written twice in a launch,
+    // so nothing a slower workgroup still reads is ever overwritten); every epoch has its own row flags (n_rows apart), partial-sum
+    // slots and their flags (slots_per_epoch apart) and sample ids (ids_epoch_stride apart).  A row of the first matrix is, from
+    // the second epoch on, a row the launch's previous epoch wrote: awaited in that epoch's flags, read at agent scope.
+    uint32_t wgs_per_epoch, n_rows, slots_per_epoch;
+    uint64_t ring_stride, ids_epoch_stride;
 };
 
 // a workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global load and store of the wave
@@ -1242,23 +1272,40 @@ constexpr uint32_t kWideJobsLds = 64;  // a workgroup's first jobs are staged in
 // EARLY ("wide_samples_early"): the sample rows this launch writes itself are awaited BEFORE the first round's neighbour waits and the
 // samples' scalars are computed ahead of them; otherwise both stay behind the neighbours.  (Two kernels, not a run-time switch: with
 // both forms inlined the kernel grew enough to run 7 % slower on RMAT-20.)
-template <int OPT, int LPI, int NB, int U, bool FULL, bool EARLY>
+// MODE 2: EARLY, and the launch may chain several epochs (WideArgs::wgs_per_epoch; its own kernel for the same reason -- the plain
+// form must not carry that code -- and because it needs ~170 registers: 2 waves per SIMD, which costs nothing where a launch is a chain).
+template <int OPT, int LPI, int NB, int U, bool FULL, int MODE>
 #ifndef F2V_WIDE_WAVES
 #define F2V_WIDE_WAVES 3
 #endif
-__global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (OPT == 5 ? F2V_WIDE_WAVES : 3) : 1) void qwide_chain_kernel(const WideArgs w) {
+__global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (MODE == 2 ? 2 : OPT == 5 ? F2V_WIDE_WAVES : 3) : 1) void qwide_chain_kernel(const WideArgs w) {
+    constexpr bool EARLY = MODE >= 1, EPOCHS = MODE == 2;
     constexpr uint32_t DP = 4u * LPI * NB, IPW = 64u / LPI, IPB = 4u * IPW;  // padded dims; lane groups per wavefront / workgroup
     constexpr uint32_t PSLOTS = IPB > 32u ? IPB : 32u;                       // piece slots: one phase of rounds
     constexpr uint32_t C4 = DP / 4u;                                          // 16-byte pieces per (padded) row
-    const WideDesc bd = w.wg[blockIdx.x];
+    uint32_t ep = 0u, wgi = blockIdx.x;  // (uniform)
+    if (EPOCHS && w.wgs_per_epoch != 0u) {
+        ep = blockIdx.x / w.wgs_per_epoch;
+        wgi = blockIdx.x - ep * w.wgs_per_epoch;
+    }
+    const WideDesc bd = w.wg[wgi];
     StepArgs a = w.base;
+    const uint32_t *prev_flags = nullptr;  // the previous epoch's row flags (second epoch of a launch onwards; always null unless EPOCHS)
+    if (EPOCHS && w.wgs_per_epoch != 0u) {
+        a.X = w.base.X + (size_t)ep * w.ring_stride;
+        a.Xn = const_cast<float *>(a.X) + w.ring_stride;
+        a.rowflag = w.base.rowflag + (size_t)ep * w.n_rows;
+        a.partials = w.base.partials + (size_t)ep * w.slots_per_epoch * w.base.D;
+        a.ready = w.base.ready + (size_t)ep * w.slots_per_epoch;
+        if (ep != 0u) prev_flags = a.rowflag - w.n_rows;
+    }
     a.batch_lo = bd.lo;
     a.upd_rows = bd.lo - a.upd_lo;      // rows [upd_lo, this minibatch's first row) are read from the second matrix ...
     a.chain_rows = bd.lo - a.chain_lo;  // ... those from chain_lo on after waiting for their flag
 #ifdef F2V_TEST_HOOKS
     if (a.test_nowait & 1u) a.chain_rows = 0u;  // f2v_test_chain_nowait (further bits: timing experiments, results WRONG)
 #endif
-    a.sample_ids = w.ids + (size_t)bd.index * w.ids_stride;
+    a.sample_ids = w.ids + (EPOCHS ? (size_t)ep * w.ids_epoch_stride : (size_t)0) + (size_t)bd.index * w.ids_stride;
     const uint32_t D = FULL ? DP : a.D;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t t = lane & (LPI - 1u), q = lane / LPI;
@@ -1304,7 +1351,7 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (OPT == 5 ? F2V_WIDE_WAV
     uint32_t late = 0;  // (uniform)
     if (lds_samples) {
         for (uint32_t sidx = 0; sidx < a.ns; ++sidx)
-            if ((a.sample_ids[sidx] - a.chain_lo) < a.chain_rows) late |= 1u << sidx;
+            if ((a.sample_ids[sidx] - a.chain_lo) < a.chain_rows || prev_flags != nullptr) late |= 1u << sidx;
         for (uint32_t k = threadIdx.x; k < a.ns * C4; k += 256u) {
             const uint32_t sidx = k / C4, c4 = k % C4;
             if ((late >> sidx) & 1u) continue;
@@ -1320,7 +1367,7 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (OPT == 5 ? F2V_WIDE_WAV
             if (!(FULL || 4u * c4 < D)) {
                 smp[sidx][c4] = make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
-                bad = wait_row(a, sj) || bad;
+                bad = wait_row_at(a, (sj - a.chain_lo) < a.chain_rows ? a.rowflag : prev_flags, sj) || bad;
                 smp[sidx][c4] = load16_agent(row_src(a, sj, D) + 4 * c4);
             }
         }
@@ -1354,7 +1401,13 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (OPT == 5 ? F2V_WIDE_WAV
         const WJob jl = job_at(n_jobs - 1u);
         if (jl.kind == kJobRow && jl.pass_len == 1u) {
             xi_pre_for = n_jobs - 1u;
-            if (threadIdx.x < D) xi_pre = a.X[(size_t)jl.row * D + threadIdx.x];
+            if (prev_flags != nullptr) {  // (the row's own last value is the previous epoch's: awaited, agent scope)
+                if (wait_row_at(a, prev_flags, jl.row)) wg_bad = 1u;
+                lds_barrier();
+                if (wg_bad) return;  // (uniform: read behind the barrier)
+                if (threadIdx.x < D)
+                    xi_pre = __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const uint32_t *>(a.X + (size_t)jl.row * D + threadIdx.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            } else if (threadIdx.x < D) xi_pre = a.X[(size_t)jl.row * D + threadIdx.x];
         }
     }
 
@@ -1390,7 +1443,12 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (OPT == 5 ? F2V_WIDE_WAV
                 };
                 if (d < D) {  // (D is a multiple of 32 in chained launches: a wavefront's quads are live or idle as a whole)
                     float xi1 = 0.f;
-                    if (OPT == 5 && jb.kind == kJobRow) xi1 = (xi_pre_for == jc) ? xi_pre : a.X[(size_t)jb.row * D + d];
+                    if (OPT == 5 && jb.kind == kJobRow) {
+                        // (a launch that chains epochs: the row's pieces in this workgroup have waited for its previous value already)
+                        if (xi_pre_for == jc) xi1 = xi_pre;
+                        else if (prev_flags != nullptr) xi1 = __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const uint32_t *>(a.X + (size_t)jb.row * D + d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        else xi1 = a.X[(size_t)jb.row * D + d];
+                    }
 #ifdef F2V_TEST_HOOKS
                     const bool skip_sums = (a.test_nowait & 8u) != 0u;
 #else
@@ -1479,7 +1537,7 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (OPT == 5 ? F2V_WIDE_WAV
                     };
                     for (uint32_t c = tl; 4u * c < D; c += 32u) {
                         float4 xi4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (OPT == 5 && jb.kind == kJobRow) xi4 = *reinterpret_cast<const float4 *>(a.X + (size_t)jb.row * D + 4u * c);
+                        if (OPT == 5 && jb.kind == kJobRow) xi4 = prev_flags != nullptr ? load16_agent(a.X + (size_t)jb.row * D + 4u * c) : *reinterpret_cast<const float4 *>(a.X + (size_t)jb.row * D + 4u * c);
 #ifdef F2V_TEST_HOOKS
                         const bool skip_sums = (a.test_nowait & 8u) != 0u;
 #else
@@ -1543,11 +1601,14 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (OPT == 5 ? F2V_WIDE_WAV
         const uint32_t cnt = idle ? 0u : it.cnt;
 
         float xi[NB][4], Y[NB][4];
+        bool xi_bad = false;
         {
             const float *src = a.X + (size_t)row * D + t * 4;
+            if (prev_flags != nullptr && !idle) xi_bad = wait_row_at(a, prev_flags, row);  // (its own last value: the previous epoch's)
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                const float4 v = (FULL || 4u * LPI * b + 4u * t < D) ? *reinterpret_cast<const float4 *>(src + 4 * LPI * b) : make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (FULL || 4u * LPI * b + 4u * t < D) v = prev_flags != nullptr ? load16_agent(src + 4 * LPI * b) : *reinterpret_cast<const float4 *>(src + 4 * LPI * b);
                 xi[b][0] = v.x; xi[b][1] = v.y; xi[b][2] = v.z; xi[b][3] = v.w;
             }
         }
@@ -1566,7 +1627,7 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (OPT == 5 ? F2V_WIDE_WAV
             const float degi = a.unit_degi ? 1.0f : (float)(1.0 / (double)(gdeg + 1u));  // algorithms.cpp:854
             c0 = (double)(a.lr * degi);
         }
-        bool bad = false, quit = false;
+        bool bad = xi_bad, quit = false;
         float cs[EARLY ? kLdsSamples : 1];  // EARLY: the samples' scalars (pair_coef_q), computed while the neighbours are still on their way
         // (First round only) the sample rows this launch writes are awaited and staged.  EARLY -- where the minibatches of a launch
         // are one dependency chain (a small graph) -- this happens behind the round's gathers and IN FRONT of its neighbour waits: a
@@ -1601,7 +1662,7 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (OPT == 5 ? F2V_WIDE_WAV
             return false;
         };
         qprocess_pre<OPT, LPI, NB, U, FULL>(a, a.nbr_ids + it.nb, cnt, wave_max_of_items<LPI>(cnt), t, D, xi, Y, c0, table, bad, jpre,
-                                            a.nbr_ids + itn.nb, (itn.flags & kItemIdle) ? 0u : itn.cnt, between);
+                                            a.nbr_ids + itn.nb, (itn.flags & kItemIdle) ? 0u : itn.cnt, between, prev_flags);
         if constexpr (!EARLY) (void)stage_late();
         if (quit) return;
         if (lds_samples) {

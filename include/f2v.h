@@ -77,7 +77,10 @@ int f2v_get_embeddings(f2v_handle h, float *x_out);
  * through HBM and combine-tree nodes, "wide_rows" (262144) rows per launch; same pieces, same fan-in groups, same results (batch 256: 2.0 -> 4.3 G
  * edges/s); needs 2 <= "hub_fanin" <= 32; "wide_phases", "wide_rounds", "wide_span", "wide_finish", "wide_order" (where a minibatch's whole-row
  * workgroups go: measured neutral), "wide_min_width" (0 = automatic) shape its
- * workgroup programs; "wide_samples_early" (-1 = automatic: small graphs): the sample rows a launch itself writes are awaited before
+ * workgroup programs; "wide_epochs" (0 = automatic: 32 on graphs of up to 2 M nonzeros that one launch covers, else 1): that many EPOCHS of options 5 / 6 run in
+ * one launch -- a ring of matrices, epoch e reads matrix e and writes matrix e + 1 behind its own row flags; same results, and what was a
+ * launch boundary per epoch becomes one more hop of the dependency chain ("last_wide_epochs" answers what the last f2v_train did);
+ * "wide_samples_early" (-1 = automatic: small graphs): the sample rows a launch itself writes are awaited before
  * the first neighbour waits instead of after them (placement in time only); "last_train_form" answers how the last f2v_train launched (0 one launch per minibatch, 1 chained, 2 wide), "last_wide_width"
  * the sub-wave layout a wide run used, "last_wide_early" whether it ran the kernel's EARLY form; "class_cut" (default 1): a split row's pieces also end where its ascending neighbour ids cross
  * from one eighth of the id range into the next (part of the summation order, restated by the oracle; it is what makes

@@ -457,6 +457,42 @@ def test_wide_form_equals_the_other_launch_forms(F, option, dim, chunk, fanin, t
         O.set_fanin(32)
 
 
+@pytest.mark.parametrize("graph,option,dim,batch,epochs", [("cora", 5, 128, 256, 16), ("cora", 5, 16, 256, 5), ("cora", 6, 64, 384, 3), ("karate", 5, 128, 8, 7),
+                                                            ("rmat13", 5, 128, 128, 4), ("rmat13", 6, 32, 256, 2), ("cora", 5, 256, 100, 64)])
+def test_epochs_chained_in_one_launch_equal_one_launch_per_epoch(F, graph, option, dim, batch, epochs):
+    """ "wide_epochs": on a graph that one wide-form launch covers, several EPOCHS run in one launch -- a ring of matrices (epoch e reads
+    matrix e, writes matrix e + 1), per-epoch row flags / partial-sum slots / sample ids, every row of the previous epoch awaited and read
+    at agent scope.  Same bits as one launch per epoch (and as the oracle), for epoch counts that do and do not divide the run, with
+    rows of several fan-in groups (helpers and finishers) and narrow rows; the statistics count every epoch; a second call continues."""
+    _need_round_robin_dispatch(F)
+    from force2vec_amd.graph import rmat_csr
+    if graph == "rmat13":
+        rowptr, colids = rmat_csr(13, 8, seed=6)
+    else:
+        rowptr, colids = F.read_mtx(golden_graph_path(graph + ".mtx"))
+    iters = 11
+    res, launches = {}, {}
+    for e in (epochs, 1):
+        eng = F.Engine(rowptr, colids, dim)
+        eng.set_param("hub_chunk", 4)
+        eng.set_param("wide_epochs", e)
+        eng.srand(1)
+        eng.init_embeddings(0 if option == 5 else 1)
+        eng.train(option, iters, batch)
+        assert eng.get_param("last_train_form") == 2
+        st = eng.stats()
+        assert st["rows"] == iters * (len(rowptr) - 1) and st["nnz"] == iters * len(colids)
+        launches[e] = st["step_launches"]
+        assert (eng.get_param("last_wide_epochs") > 1) == (e > 1)
+        eng.train(option, 2, batch)
+        res[e] = eng.get_embeddings()
+        eng.close()
+    assert launches[1] == iters and launches[epochs] == -(-iters // epochs)
+    assert np.array_equal(res[epochs], res[1]) and np.isfinite(res[1]).all()
+    want = O.train(option, rowptr, colids, dim, iters + 2, batch, order=O.ORDER_TREE, chunk=4)
+    assert np.array_equal(res[epochs], want)
+
+
 def _csr(n, edges):
     r = np.array([e[0] for e in edges], dtype=np.int64)
     c = np.array([e[1] for e in edges], dtype=np.int64)
