@@ -149,7 +149,7 @@ void sm_table_host(float *t) {
 // prefetched a pass ahead, from stream positions PREDICTED for them (a draw at every step but those whose degree is known
 // beforehand: the start vertex, and the second vertex where the first step draws nothing); afterwards the draws each walk really
 // made are compared with the prediction, the walks up to and including the first mispredicted one are kept -- they started at
-// the right position -- and the block restarts behind it.  Same samples, same stream position afterwards (draws taken ahead are
+// the right position -- and the next block, as long as the stretch that held (doubling again while all hold), starts behind it.  Same samples, same stream position afterwards (draws taken ahead are
 // given back, Rand::back), whatever the graph.
 #ifndef F2V_WALK_BLOCK
 #define F2V_WALK_BLOCK 32  // RMAT-20, 5.2 M steps: 8 / 16 / 32 / 64 / 128 walks side by side -> 210 / 178 / 168 / 205 / 350 ms where the serial loop takes 530
@@ -164,9 +164,34 @@ void walks_host(Rand &g, const uint32_t *rp, const uint32_t *ci, uint32_t n, uin
     uint32_t vals[V];
     uint32_t avail = 0;  // vals[0, avail): the stream's next draws
     uint32_t w[B], jj[B], off[B], used[B], predicted[B];
+    // How many walks run side by side follows how often the predictions have been failing: fewer than one walk in four (RMAT-20: one
+    // in 25) -> a full block, the memory latency is what there is to hide; more than one in two (cora: half the steps draw nothing, and
+    // the graph sits in the cache) -> the reference's own serial loop, 64 walks at a time, which no block of doomed walks beats.
+    uint32_t width = B, seen = 0, missed = 0;
     for (uint32_t i0 = 0; i0 < n;) {
-        const uint32_t nb = std::min(B, n - i0);
-        while (avail < V) vals[avail++] = (uint32_t)g.next();
+        if (width == 1u) {
+            while (avail) { g.back(); avail--; }
+            const uint32_t stop = std::min(n, i0 + 64u);
+            for (; i0 < stop; i0++) {
+                uint32_t v = i0, draws = 0;
+                for (uint32_t s = 0; s < L; s++) {
+                    const uint32_t lo = rp[v], deg = rp[v + 1] - lo;
+                    uint32_t j = v;
+                    if (deg > 2) { j = g.index(rp[v + 1] - 1, lo); draws++; }
+                    else if (deg == 2) j = lo;
+                    if (j > last) j = last;
+                    v = ci[j];
+                    walks[(size_t)i0 * L + s] = v;
+                }
+                seen++;
+                missed += draws < L - 1u ? 1u : 0u;  // (what a block would have mispredicted, more or less: a step past the first drew nothing)
+            }
+            if (seen >= 512u) { seen >>= 1; missed >>= 1; }
+            width = 4u * missed <= seen ? B : 2u * missed <= seen ? 4u : 1u;
+            continue;
+        }
+        const uint32_t nb = std::min(width, n - i0);
+        while (avail < nb * L) vals[avail++] = (uint32_t)g.next();
         // predicted draws per walk
         for (uint32_t t = 0; t < nb; t++) {
             const uint32_t i = i0 + t, deg = rp[i + 1] - rp[i];
@@ -212,6 +237,10 @@ void walks_host(Rand &g, const uint32_t *rp, const uint32_t *ci, uint32_t n, uin
         avail -= consumed;
         memmove(vals, vals + consumed, avail * sizeof(uint32_t));
         i0 += valid;
+        seen += valid;
+        missed += valid < nb ? 1u : 0u;
+        if (seen >= 512u) { seen >>= 1; missed >>= 1; }
+        width = 4u * missed <= seen ? B : 2u * missed <= seen ? 4u : 1u;
     }
     while (avail--) g.back();
 }
