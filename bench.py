@@ -193,7 +193,7 @@ def kernel_name(args, pushing, form, wide_width=0, wide_early=0):
         w = max(w, wide_width)  # the wide form may run narrow rows on a wider layout ("wide_min_width")
     opt, lpi, nb, u, full = 5 if args.option in (5, 8, 11) else 6, min(16, w // 4), max(1, w // 64), 4 if w >= 128 else 8, "true" if w == args.dim else "false"
     if form == 2 and not pushing:
-        return "f2v::qwide_chain_kernel<%d, %d, %d, %d, %s, %s>" % (opt, lpi, nb, u, full, "true" if wide_early else "false")
+        return "f2v::qwide_chain_kernel<%d, %d, %d, %d, %s, %d>" % (opt, lpi, nb, u, full, wide_early)  # MODE: 0 plain, 1 EARLY, 2 EARLY + epochs chained
     if form == 1 and not pushing:
         return "f2v::qstep_chain_kernel<%d, %d, %d, %d, %s>" % (opt, lpi, nb, u, full)
     return "f2v::qstep_kernel<%d, %d, %d, %d, %s, %s>" % (opt, lpi, nb, u, "true" if pushing else "false", full)
@@ -566,7 +566,7 @@ def main():
     main_settle = state["settle_epochs"]
     main_form = eng.get_param("last_train_form")
     main_wide_width = eng.get_param("last_wide_width") if main_form == 2 else 0
-    main_wide_early = eng.get_param("last_wide_early") if main_form == 2 else 0
+    main_wide_early = (2 if eng.get_param("last_wide_epochs") > 1 else eng.get_param("last_wide_early")) if main_form == 2 else 0
     note(rank, "timed region done: %.3f ms per epoch" % (dt / args.steps * 1e3))
     # rForce2Vec attracts along 5 walk samples per vertex, not along the CSR's nonzeros
     units = 5 * n if args.option in (7, 10) else nnz
