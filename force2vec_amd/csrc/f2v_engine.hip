@@ -159,6 +159,7 @@ struct f2v_ctx {
     float *d_ring = nullptr, *d_ring_partials = nullptr;
     uint32_t *d_ring_flags = nullptr, *d_ring_ready = nullptr;
     uint32_t ring_epochs = 0;   // epochs the ring buffers are sized for
+    bool ring_refused = false;  // the device had no room for them
     size_t ring_slots = 0;      // partial-sum slots per epoch they are sized for
     int wide_samples_early = -1;  // "wide_samples_early": StepArgs::samples_early; -1 = automatic (graphs of up to 2 M nonzeros: the launch is one dependency chain)
     uint32_t wide_rounds = 0;   // rounds per phase of such a workgroup (0: one for minibatches of up to 512 rows, else as many as fill the piece slots)
@@ -1404,8 +1405,39 @@ int launch_chain(f2v_ctx *c, int math, const ChainPlan &plan, const uint32_t *d_
 // of epochs + 1 matrices, epoch e reads matrix e and writes matrix e + 1 behind its own row flags, and the last one is copied back
 // (two 1-MB copies per launch on a graph like cora, where the launch boundary they replace is a third of an epoch).
 int launch_wide(f2v_ctx *c, int math, const WidePlan &plan, const uint32_t *d_ids_epoch, uint32_t ids_stride, uint32_t ns, float lr, int bs_mode,
-                uint32_t epochs = 1, uint64_t ids_epoch_stride = 0) {
+                uint32_t *epochs_io = nullptr, uint64_t ids_epoch_stride = 0) {
     int rc;
+    uint32_t epochs = epochs_io ? *epochs_io : 1u;
+    if (epochs > 1 && (c->ring_epochs < epochs || c->ring_slots < std::max<size_t>(plan.n_slots, 1))) {
+        // the ring of matrices (and the per-epoch flags and partial sums): where the device has no room for it, one epoch per launch
+        HIPC(hipStreamSynchronize(c->stream));
+        for (void *p : {(void *)c->d_ring, (void *)c->d_ring_partials, (void *)c->d_ring_flags, (void *)c->d_ring_ready})
+            if (p) (void)hipFree(p);
+        c->d_ring = c->d_ring_partials = nullptr;
+        c->d_ring_flags = c->d_ring_ready = nullptr;
+        const uint32_t cap = std::max(epochs, c->ring_epochs);
+        const size_t slots = std::max<size_t>(std::max<size_t>(plan.n_slots, c->ring_slots), 1), mat = (size_t)c->n * c->D;
+        c->ring_epochs = 0;
+        c->ring_slots = 0;
+        if (hipMalloc((void **)&c->d_ring, (size_t)(cap + 1) * mat * sizeof(float)) != hipSuccess ||
+            hipMalloc((void **)&c->d_ring_partials, (size_t)cap * slots * c->D * sizeof(float)) != hipSuccess ||
+            hipMalloc((void **)&c->d_ring_flags, (size_t)cap * c->n * sizeof(uint32_t)) != hipSuccess ||
+            hipMalloc((void **)&c->d_ring_ready, (size_t)cap * slots * sizeof(uint32_t)) != hipSuccess) {
+            (void)hipGetLastError();
+            for (void *p : {(void *)c->d_ring, (void *)c->d_ring_partials, (void *)c->d_ring_flags, (void *)c->d_ring_ready})
+                if (p) (void)hipFree(p);
+            c->d_ring = c->d_ring_partials = nullptr;
+            c->d_ring_flags = c->d_ring_ready = nullptr;
+            c->ring_refused = true;  // (f2v_train stops asking)
+            epochs = 1;
+        } else {
+            HIPC(hipMemsetAsync(c->d_ring_flags, 0, (size_t)cap * c->n * sizeof(uint32_t), c->stream));  // 0 is no launch's sequence number
+            HIPC(hipMemsetAsync(c->d_ring_ready, 0, (size_t)cap * slots * sizeof(uint32_t), c->stream));
+            c->ring_epochs = cap;
+            c->ring_slots = slots;
+        }
+    }
+    if (epochs_io) *epochs_io = epochs;
     const bool ring = epochs > 1;
     if (ring || (c->upd_hi != c->upd_lo && plan.lo != c->upd_hi)) {
         if ((rc = flush_pending(c)) != F2V_OK) return rc;
@@ -1413,24 +1445,6 @@ int launch_wide(f2v_ctx *c, int math, const WidePlan &plan, const uint32_t *d_id
     const size_t matrix = (size_t)c->n * c->D;
     if (ring) {
         if (plan.lo != 0 || plan.hi != c->n || plan.n_node_wgs != 0) return fail(F2V_ESTATE, "launch_wide: epochs can only be chained where one launch covers the graph");
-        if (c->ring_epochs < epochs || c->ring_slots < std::max<size_t>(plan.n_slots, 1)) {
-            HIPC(hipStreamSynchronize(c->stream));
-            for (void *p : {(void *)c->d_ring, (void *)c->d_ring_partials, (void *)c->d_ring_flags, (void *)c->d_ring_ready})
-                if (p) (void)hipFree(p);
-            c->d_ring = c->d_ring_partials = nullptr;
-            c->d_ring_flags = c->d_ring_ready = nullptr;
-            const uint32_t cap = std::max(epochs, c->ring_epochs);
-            const size_t slots = std::max<size_t>(std::max<size_t>(plan.n_slots, c->ring_slots), 1);
-            c->ring_epochs = 0;
-            HIPC(hipMalloc((void **)&c->d_ring, (size_t)(cap + 1) * matrix * sizeof(float)));
-            HIPC(hipMalloc((void **)&c->d_ring_partials, (size_t)cap * slots * c->D * sizeof(float)));
-            HIPC(hipMalloc((void **)&c->d_ring_flags, (size_t)cap * c->n * sizeof(uint32_t)));
-            HIPC(hipMalloc((void **)&c->d_ring_ready, (size_t)cap * slots * sizeof(uint32_t)));
-            HIPC(hipMemsetAsync(c->d_ring_flags, 0, (size_t)cap * c->n * sizeof(uint32_t), c->stream));  // 0 is no launch's sequence number
-            HIPC(hipMemsetAsync(c->d_ring_ready, 0, (size_t)cap * slots * sizeof(uint32_t), c->stream));
-            c->ring_epochs = cap;
-            c->ring_slots = slots;
-        }
         HIPC(hipMemcpyAsync(c->d_ring, c->d_X[c->cur], matrix * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     }
     WideArgs wa{};
@@ -2707,8 +2721,8 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
                 if ((rc = upload_plans(c)) != F2V_OK) return rc;
                 // epochs chained in one launch: the plan covers the graph, every epoch's sample ids are on the device, no walks, no marks
                 uint32_t E = 1;
-                if (epochs_max > 1 && K >= nb && plan.n_node_wgs == 0) E = std::min(epochs_max, iters - it);
-                if ((rc = launch_wide(c, math, plan, d_epoch_ids, (uint32_t)stride, ns, lr, bs_mode, E, per_epoch)) != F2V_OK) return rc;
+                if (epochs_max > 1 && K >= nb && plan.n_node_wgs == 0 && !c->ring_refused) E = std::min(epochs_max, iters - it);
+                if ((rc = launch_wide(c, math, plan, d_epoch_ids, (uint32_t)stride, ns, lr, bs_mode, &E, per_epoch)) != F2V_OK) return rc;
                 it += E - 1;
             }
         } else if (chained) {
