@@ -1419,7 +1419,11 @@ int launch_wide(f2v_ctx *c, int math, const WidePlan &plan, const uint32_t *d_id
         const size_t slots = std::max<size_t>(std::max<size_t>(plan.n_slots, c->ring_slots), 1), mat = (size_t)c->n * c->D;
         c->ring_epochs = 0;
         c->ring_slots = 0;
-        if (hipMalloc((void **)&c->d_ring, (size_t)(cap + 1) * mat * sizeof(float)) != hipSuccess ||
+        bool refuse = false;
+#ifdef F2V_TEST_HOOKS
+        refuse = getenv("F2V_TEST_RING_REFUSE") != nullptr;  // fault injection: as if the device had no room for the ring
+#endif
+        if (refuse || hipMalloc((void **)&c->d_ring, (size_t)(cap + 1) * mat * sizeof(float)) != hipSuccess ||
             hipMalloc((void **)&c->d_ring_partials, (size_t)cap * slots * c->D * sizeof(float)) != hipSuccess ||
             hipMalloc((void **)&c->d_ring_flags, (size_t)cap * c->n * sizeof(uint32_t)) != hipSuccess ||
             hipMalloc((void **)&c->d_ring_ready, (size_t)cap * slots * sizeof(uint32_t)) != hipSuccess) {

@@ -3,7 +3,9 @@
  * force2vec_amd/libf2v_selftest.so, the same sources built with -DF2V_TEST_HOOKS (Makefile), which tests/ and a few
  * tools/ load instead of libf2v.so where they need fault injection or a look inside.  That build also understands
  * the environment variable F2V_PUSH_CHAOS=<seed>: every rank of f2v_train_sharded drains its stream and sleeps up to
- * 3 ms at random minibatches (other ones on every rank) -- the protocol test under rank skew.
+ * 3 ms at random minibatches (other ones on every rank) -- the protocol test under rank skew; F2V_TEST_WITHHOLD_SLOT / F2V_TEST_WITHHOLD_ROW
+ * (f2v_test_withhold_flag / _row from outside the process: the CLI's fault tests) and F2V_TEST_RING_REFUSE (the ring of matrices of
+ * "wide_epochs" is refused as if the device had no room: f2v_train falls back to one epoch per launch).
  */
 #ifndef F2V_TEST_H_
 #define F2V_TEST_H_

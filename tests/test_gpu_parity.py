@@ -493,6 +493,29 @@ def test_epochs_chained_in_one_launch_equal_one_launch_per_epoch(F, graph, optio
     assert np.array_equal(res[epochs], want)
 
 
+def test_chained_epochs_fall_back_where_the_ring_does_not_fit(F, monkeypatch):
+    """The ring of matrices is an extra: where the device refuses it (self-test build: F2V_TEST_RING_REFUSE) f2v_train runs one epoch
+    per launch, same bits, and does not ask again."""
+    _need_round_robin_dispatch(F)
+    rowptr, colids = F.read_mtx(golden_graph_path("cora.mtx"))
+    res = []
+    for refuse in (True, False):
+        if refuse:
+            monkeypatch.setenv("F2V_TEST_RING_REFUSE", "1")
+        else:
+            monkeypatch.delenv("F2V_TEST_RING_REFUSE", raising=False)
+        eng = F.Engine(rowptr, colids, 64, selftest=True)
+        eng.srand(1)
+        eng.init_embeddings(0)
+        eng.train(5, 9, 256)
+        assert eng.get_param("last_train_form") == 2 and (eng.get_param("last_wide_epochs") > 1) == (not refuse)
+        assert eng.stats()["step_launches"] == (9 if refuse else 1)
+        eng.train(5, 3, 256)
+        res.append(eng.get_embeddings())
+        eng.close()
+    assert np.array_equal(res[0], res[1])
+
+
 def _csr(n, edges):
     r = np.array([e[0] for e in edges], dtype=np.int64)
     c = np.array([e[1] for e in edges], dtype=np.int64)
