@@ -6,11 +6,16 @@ CSRC = force2vec_amd/csrc
 # -ffp-contract=off: the reference's mul/add pairs are separate roundings (x86-64 without FMA);
 # parity with the oracle depends on it.
 CXXFLAGS = -O3 -std=c++17 -fPIC -pthread -Iinclude -I$(CSRC) -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result
-HIPFLAGS = --offload-arch=$(ARCH) $(CXXFLAGS)
+# The libraries export the C ABI of include/f2v.h (F2V_API) and nothing else: hidden visibility for every other symbol -- the
+# kernels' host-side launch stubs included -- and -Bsymbolic, so that a second build of the library in the same process (the
+# self-test build preloaded under the CLI, an older libf2v of another package) can neither interpose on this one's internals
+# nor be interposed on.  (Round 3's "memory access fault ... address 0x1000": DESIGN section 3.)
+LIBFLAGS = -fvisibility=hidden -fvisibility-inlines-hidden -Wl,-Bsymbolic -Wl,--exclude-libs,ALL -Wl,--version-script=$(CSRC)/libf2v.map
+HIPFLAGS = --offload-arch=$(ARCH) $(CXXFLAGS) $(LIBFLAGS)
 LIB = force2vec_amd/libf2v.so
 # the same sources with the self-test hooks of include/f2v_test.h compiled in (tests/, tools/ only)
 TESTLIB = force2vec_amd/libf2v_selftest.so
-SRCS = $(CSRC)/f2v_engine.hip $(CSRC)/f2v_kernels.hip.h $(CSRC)/f2v_host.cpp $(CSRC)/f2v_internal.h include/f2v.h
+SRCS = $(CSRC)/f2v_engine.hip $(CSRC)/f2v_kernels.hip.h $(CSRC)/f2v_host.cpp $(CSRC)/f2v_internal.h include/f2v.h $(CSRC)/libf2v.map
 
 all: $(LIB) $(TESTLIB) bin/Force2Vec bin/Force2Vec_selftest
 

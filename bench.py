@@ -95,7 +95,7 @@ def write_mtx_fast(path, n, src, dst):
         write_mtx_symmetric(path, n, src, dst)
 
 
-def cpu_baseline(args):
+def cpu_baseline(args, opt7=None):
     """The reference on this box's host cores, on a bounded sample of the same workload: the north-star's 10 M-edge
     power-law graph (RMAT scale args.cpu_scale = 20 by default: the benchmark's own graph, 15.7 M undirected edges), same
     D / ns / lr / batch, a few epochs.  T(iters=k) - T(iters=0) strips the reference's in-timer initialisation and leaves
@@ -137,6 +137,20 @@ def cpu_baseline(args):
             threads = best
             k = max(2, args.cpu_iters)
             tk = run(mtx, k, threads)
+            if opt7 is not None:
+                # the reference's own option 7 (rForce2Vec; option 10 is its AVX512 twin) on the same graph: T(6) - T(0), 5 walk samples per vertex and epoch
+                try:
+                    o7 = 10 if avx512 else 7
+
+                    def run7(iters, th):
+                        out = run_ref(O, mtx, td, o7, iters, args, th, avx512)
+                        return float([l for l in out.splitlines() if "Wall time required" in l][0].split(":")[-1].split()[0])
+                    t70 = run7(0, 1)
+                    t7 = run7(6, threads) - t70
+                    opt7.update({"reference_cpu_option": o7, "reference_cpu_threads": threads, "reference_cpu_ms_per_epoch": t7 / 6 * 1e3,
+                                 "reference_cpu_pairs_per_s": 5.0 * n * 6 / max(t7, 1e-9)})
+                except Exception as ex:  # noqa: BLE001
+                    opt7["reference_cpu_ms_per_epoch"] = "failed: %r" % (ex,)
         val = nnz * k / max(tk - t0, 1e-9)
         return {"value": val, "unit": "edges/s", "cores": threads, "kind": "reference",
                 "sample": "%s; oracle/_ref option %d%s, %d epochs in %.2fs, -threads %d (best of %s in a 3-epoch scan on the same graph; %d-core host)"
@@ -197,6 +211,62 @@ def kernel_name(args, pushing, form, wide_width=0, wide_early=0):
     if form == 1 and not pushing:
         return "f2v::qstep_chain_kernel<%d, %d, %d, %d, %s>" % (opt, lpi, nb, u, full)
     return "f2v::qstep_kernel<%d, %d, %d, %d, %s, %s>" % (opt, lpi, nb, u, "true" if pushing else "false", full)
+
+
+def live_traffic(args, kname, budget_s):
+    """`roofline.traffic` measured BY THIS RUN: separate `rocprofv3 --pmc` passes (FETCH_SIZE; WRITE_SIZE; TCC_HIT / TCC_MISS -- never
+    combined with a trace domain other than --kernel-trace) over a short child run of this very script on the same workload, read per
+    launch of the dominant kernel.  Corrections as MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE (KiB) x 2 for 16-byte-per-lane
+    reads (128-B requests are tallied at 64 B), WRITE_SIZE (KiB) exact.  -> dict, or a string saying why it was not collected."""
+    import glob
+    if shutil.which("rocprofv3") is None:
+        return "rocprofv3 is not on PATH"
+    if any(k in os.environ for k in ("ROCPROFILER_LIBRARY_CTOR", "ROCP_TOOL_LIBRARIES", "ROCPROF_OUTPUT_PATH")) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return "this run is itself under a profiler"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from parse_pmc import counters
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--settle-ms", "0", "--extra-batches=", "--config5-scale", "0", "--config4", "0",
+             "--cora", "0", "--sustained-s", "0", "--verify-rows", "0", "--no-cpu-baseline", "--live-pmc", "0", "--option7", "0", "--no-ceilings",
+             "--batch", str(args.batch), "--scale", str(args.scale), "--dim", str(args.dim), "--option", str(args.option), "--hub-chunk", str(args.hub_chunk)]
+    for kv in args.param:
+        child += ["--param", kv]
+    short = kname.split("::")[-1].split("<")[0]
+    out, t_start = {}, time.time()
+    td = tempfile.mkdtemp(prefix="f2v_pmc_")
+    try:
+        for name, ctrs in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("l2", ["TCC_HIT_sum", "TCC_MISS_sum"])):
+            left = budget_s - (time.time() - t_start)
+            if left < 20:
+                out["note"] = "stopped before the %s pass: the time budget of %d s was used up" % (name, budget_s)
+                break
+            d = os.path.join(td, name)
+            env = dict(os.environ, TMPDIR="/tmp", F2V_BENCH_QUIET="1")
+            try:
+                r = subprocess.run(["rocprofv3", "--pmc"] + ctrs + ["--kernel-trace", "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
+                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=left)
+            except subprocess.TimeoutExpired:
+                out["note"] = "the %s pass did not end within the time budget" % name
+                break
+            if r.returncode != 0:
+                out["note"] = "the %s pass ended with code %d: %s" % (name, r.returncode, r.stderr[-300:])
+                break
+            c, nd = counters(d, kname.split("::")[-1], skip_first=0)  # (the name as the profiler prints it: template arguments included)
+            if not nd:
+                c, nd = counters(d, short, skip_first=0)
+            # the child's launches of the dominant kernel at THIS batch size only (its verification / other kernels are switched off)
+            out.update(c)
+            out["launches_" + name] = nd
+        if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
+            res = {"traffic": out["FETCH_SIZE"] * 1024.0 * 2.0 + out["WRITE_SIZE"] * 1024.0, "fetch_bytes": out["FETCH_SIZE"] * 1024.0 * 2.0, "write_bytes": out["WRITE_SIZE"] * 1024.0,
+                   "launches_sampled": out.get("launches_fetch"), "seconds": time.time() - t_start}
+            if out.get("TCC_MISS_sum"):
+                res["l2_hit_rate"] = out["TCC_HIT_sum"] / (out["TCC_HIT_sum"] + out["TCC_MISS_sum"])
+            if "note" in out:
+                res["note"] = out["note"]
+            return res
+        return out.get("note", "no counters of %s in the profiler's output" % short)
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
 
 
 def run_ref(O, mtx, td, option, iters, args, cores, avx512):
@@ -277,6 +347,11 @@ def main():
                          "(also: environment variable F2V_ORKUT_MTX); otherwise a synthetic graph of com-Orkut's size stands in and the line says so")
     ap.add_argument("--cora", type=int, default=1, help="N=1: also time BASELINE configs[0] and [1] (cora, option 5, batch 256, 1200 epochs at D = 16 / 128) and "
                                                         "the reference's single-threaded option 5 beside config 0 (reported under 'extra'; 0 = skip)")
+    ap.add_argument("--live-pmc", type=int, default=60, help="N=1: roofline.traffic measured by this run -- separate rocprofv3 --pmc passes over a short child run of the same workload, "
+                                                             "within this many seconds (0 = take the figure of the committed builder-side session, profiles/traffic.json, where its key matches)")
+    ap.add_argument("--no-ceilings", action="store_true", help="skip the on-box ceilings (stream copy, row gathers) of the roofline object")
+    ap.add_argument("--option7", type=int, default=1, help="N=1: also time option 7 (rForce2Vec, parity mode: walks from the one rand() stream on the host) on the main graph, "
+                                                           "with its host walk generation alone and the reference's own option 7 beside it (reported under 'extra'; 0 = skip)")
     ap.add_argument("--sustained-s", type=float, default=5.0, help="N=1: the headline workload for this many seconds in ONE f2v_train call, with the rate second by second (0 = skip)")
     args = ap.parse_args()
 
@@ -538,6 +613,10 @@ def main():
             if sess.state["exchange"] == "push" and tune:
                 sess.tune_push(batch)
         dt, st = sess.timed(steps, warmup, batch)
+        if st is not None and st.get("recovered"):
+            # a give-up inside the timed region: f2v_train ran the call again with one launch per minibatch and tree level -- correct
+            # bits, but not the launch forms this line is about
+            failed.append("a launch of the timed region was lost and recovered from (option %d, batch %d): its time is the slow launch forms'" % (sess.option, batch))
         verified = None
         if use_dist and not args.no_verify:
             verified = sess.verify_replica()
@@ -585,6 +664,11 @@ def main():
                        "allgather": "%s all-gather of the new rows" % ("RCCL" if args.dist_backend == "nccl" else "gloo (host-bounce self-test)"),
                        "need": "%s all-to-all-v of the rows each rank reads" % ("RCCL" if args.dist_backend == "nccl" else "gloo (host-bounce self-test)")}[state["exchange"]])},
     }
+    if st is not None:
+        res["config"]["recoveries"] = int(st.get("recoveries", 0))          # give-ups f2v_train recovered from on this handle so far (0 expected)
+        res["config"]["merge_finalize"] = int(st.get("merge_finalize", 1))  # 0: the handle has fallen back to launches without in-grid waits
+        if not use_dist:
+            res["config"]["snapshot_copy_ms_per_train_call"] = st.get("snapshot_seconds", 0.0) * 1e3  # "recover": outside ms_per_step's device time, inside the wall time
     if use_dist:
         res["config"]["exchange"] = state["exchange"]
         res["config"]["replicas_bit_identical_to_1gpu_run"] = verified
@@ -615,24 +699,49 @@ def main():
                 "definition": "achieved = compulsory bytes per launch (distinct embedding rows read + rows written + neighbour ids + work items, "
                               "counted by the engine) / average launch time; frac <= 1 by construction",
                 # SURVEY 8d's count charges EVERY neighbour row to HBM: a rate of useful bytes delivered to the CUs, served by L2 + Infinity Cache + HBM together
-                "algorithmic_bytes_per_launch": alg, "algorithmic_GBs": alg / t_launch * 1e-9}
+                "algorithmic_bytes_per_launch": alg, "algorithmic_GBs": alg / t_launch * 1e-9,
+                "algorithmic_frac_note": "SURVEY 8d bytes / launch time / peak = %.2f: > 1 on a power-law graph because cache-served re-reads of hub rows are charged to HBM -- "
+                                         "a delivery rate of useful bytes (L2 + Infinity Cache + HBM together), not a fraction of the HBM roofline" % (alg / t_launch * 1e-9 / HBM_PEAK_GBS,)}
+        live = None
+        if not use_dist and args.live_pmc > 0:
+            note(rank, "roofline.traffic: rocprofv3 --pmc passes over a child run of the same workload (at most %d s)" % args.live_pmc)
+            live = live_traffic(args, kname, args.live_pmc)
+            if isinstance(live, dict):
+                roof["traffic"] = live["traffic"]
+                roof["traffic_is"] = "bytes that left the XCDs' L2s per launch: FETCH_SIZE x 2 (the guide's gfx950 correction for 16-byte-per-lane reads) + WRITE_SIZE, HBM + Infinity Cache together (rocprofv3 cannot split them on gfx950)"
+                roof["traffic_source"] = ("measured by this run: separate rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE; TCC_HIT_sum TCC_MISS_sum) over a child run of the same workload on this box, "
+                                          "%s launches of the kernel sampled per pass, %.0f s" % (live.get("launches_sampled"), live["seconds"]))
+                roof["traffic_fetch_bytes"], roof["traffic_write_bytes"] = live["fetch_bytes"], live["write_bytes"]
+                roof["l2_miss_GBs"] = live["traffic"] / t_launch * 1e-9
+                if "l2_hit_rate" in live:
+                    roof["l2_hit_rate"] = live["l2_hit_rate"]
+                roof["traffic_over_compulsory"] = live["traffic"] / comp
+                roof["hbm_bytes_per_launch_between"] = [comp, live["traffic"]]
+                if "note" in live:
+                    roof["traffic_note"] = live["note"]
+            else:
+                roof["traffic_note"] = "no live PMC pass: %s" % (live,)
         tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp) and not use_dist:
+        if os.path.exists(tp) and not use_dist and not isinstance(live, dict):
             try:
                 tj = json.load(open(tp))
                 key = {"batch": args.batch, "scale": args.scale, "dim": args.dim, "option": args.option, "hub_chunk": eng.get_param("hub_chunk"),
                        "kernel": kname, "library": F._lib.lib().f2v_version().decode()}
                 if all(tj.get(k) == v for k, v in key.items()):
                     roof["traffic"] = tj.get("l2_miss_bytes_per_launch")
+                    # NOT measured by this run: replayed from the committed PMC session of the same workload / kernel / library version
+                    roof["traffic_source"] = ("profiles/traffic.json: builder-side rocprofv3 --pmc session (tools/profile_traffic.sh, separate passes), collected %s for library '%s'; "
+                                              "replayed here because its workload / kernel / library key matches -- not a measurement of this run"
+                                              % (tj.get("collected", "in an earlier session"), tj.get("library")))
                     roof["traffic_is"] = "bytes that left the XCDs' L2s per launch (PMC: TCC_EA0_RDREQ/WRREQ, calibrated): HBM + Infinity Cache, which rocprofv3 cannot split on gfx950"
                     roof["l2_miss_GBs"] = roof["traffic"] / t_launch * 1e-9
                     roof["l2_hit_rate"] = tj.get("l2_hit_rate")
                     roof["hbm_bytes_per_launch_between"] = [comp, roof["traffic"]]
                 else:
-                    roof["traffic_note"] = "profiles/traffic.json was collected for another workload / kernel / library build: not applied"
+                    roof["traffic_note"] = (roof.get("traffic_note", "") + "; " if roof.get("traffic_note") else "") + "profiles/traffic.json was collected for another workload / kernel / library build: not applied"
             except Exception:
                 pass
-        if not use_dist:
+        if not use_dist and not args.no_ceilings:
             import ctypes
             g = ctypes.c_double()
             L = F._lib.lib()
@@ -648,6 +757,8 @@ def main():
         for b in [int(x) for x in args.extra_batches.split(",") if x]:
             k = max(1, args.steps // 2)
             dtb, stb = sess.timed(k, 1, b)
+            if stb.get("recovered"):
+                failed.append("batch %d: a launch of the timed region was lost and recovered from" % b)
             extra["batch_%d" % b] = {"edges_per_s": units * k / dtb, "ms_per_epoch": dtb / k * 1e3,
                                      "algorithmic_GBs": stb["algorithmic_bytes"] / stb["device_seconds"] * 1e-9,
                                      "compulsory_GBs": stb["compulsory_bytes"] / stb["device_seconds"] * 1e-9}
@@ -686,6 +797,29 @@ def main():
                               "per_second_edges_per_s_min": min(rates) if rates else None, "per_second_edges_per_s_max": max(rates) if rates else None,
                               "per_second_edges_per_s": rates}
         note(rank, "sustained: %d epochs in %.2f s of device time, %.2f G edges/s" % (iters, dev, units * iters / dev * 1e-9))
+    if rank == 0 and not use_dist and args.option7:
+        # option 7 (rForce2Vec) in parity mode on the same graph: its walks are draws of the ONE serial rand() stream, generated on the
+        # host (a producer thread, one epoch ahead of the device): epoch time, host generation alone, device work alone ("fast_rng":
+        # the same kernels, walks from a device-side generator -- non-parity numbers)
+        e7 = F.Engine(rowptr, colids, args.dim, device=local_rank)
+        e7.srand(1)
+        e7.init_embeddings(F._lib.INIT_UNIT)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            e7.generate_walks()
+        host_ms = (time.perf_counter() - t0) / 3 * 1e3
+        e7.train(7, 2, args.batch, 5, 0.02, 0)
+        t0 = time.perf_counter()
+        e7.train(7, 6, args.batch, 5, 0.02, 0)
+        wall_ms = (time.perf_counter() - t0) / 6 * 1e3
+        e7.set_param("fast_rng", 1)
+        e7.train(7, 2, args.batch, 5, 0.02, 0)
+        dev_ms = e7.train(7, 6, args.batch, 5, 0.02, 0) / 6 * 1e3
+        e7.close()
+        extra["option7"] = {"workload": "RMAT scale-%d (n=%d), option 7, D=%d, batch=%d, parity mode (walks from the serial rand() stream)" % (args.scale, n, args.dim, args.batch),
+                            "ms_per_epoch": wall_ms, "pairs_per_s": 5.0 * n / (wall_ms * 1e-3), "host_walk_generation_ms_per_epoch": host_ms,
+                            "device_only_ms_per_epoch_fast_rng": dev_ms}
+        note(rank, "option 7: %.1f ms per epoch (host walks alone %.1f ms, device alone %.2f ms)" % (wall_ms, host_ms, dev_ms))
     sess.close()
     del sess, eng
     if rank == 0 and not use_dist and args.cora:
@@ -719,7 +853,8 @@ def main():
                 sec = ce.train(5, 1200, 256, 5, 0.02, 0)
                 best = sec if best is None else min(best, sec)
             extra[key] = {"workload": "cora.mtx (n=%d, nnz=%d), option 5, D=%d, batch 256, 1200 epochs" % (len(crp) - 1, len(cci), dim),
-                          "seconds_device": best, "edges_per_s": len(cci) * 1200 / best, "launch_form": {0: "one launch per minibatch", 1: "chained", 2: "chained, wide form"}[ce.get_param("last_train_form")],
+                          "seconds_device": best, "edges_per_s": len(cci) * 1200 / best, "launch_form": {0: "one launch per minibatch", 1: "chained", 2: "chained, wide form", 3: "hipGraph replay"}[ce.get_param("last_train_form")],
+                          "epochs_per_launch": ce.get_param("last_wide_epochs"), "recoveries": ce.get_param("recoveries"),
                           "epochs10_max_abs_vs_reference_output": err, "epochs10_bit_identical_to_oracle": bool(np.array_equal(got, want))}
             ce.close()
         try:  # config 0 as BASELINE words it: the reference CPU path, single thread (oracle/_ref option 5 -threads 1; T(1200) - T(0) strips its in-timer init)
@@ -821,7 +956,7 @@ def main():
         res["extra"] = extra
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            res["cpu_baseline"] = cpu_baseline(args)
+            res["cpu_baseline"] = cpu_baseline(args, extra.get("option7") if args.cpu_scale == args.scale else None)
         except Exception as ex:  # the baseline is reported, never required for the GPU number
             res["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": os.cpu_count(), "kind": "reference", "sample": "failed: %r" % (ex,)}
     if failed:

@@ -18,7 +18,8 @@ f32p = C.POINTER(C.c_float)
 class Stats(C.Structure):
     _fields_ = [("step_launches", C.c_uint64), ("rows", C.c_uint64), ("nnz", C.c_uint64),
                 ("algorithmic_bytes", C.c_uint64), ("device_seconds", C.c_double),
-                ("hub_rows", C.c_uint64), ("hub_chunks", C.c_uint64), ("compulsory_bytes", C.c_uint64)]
+                ("hub_rows", C.c_uint64), ("hub_chunks", C.c_uint64), ("compulsory_bytes", C.c_uint64),
+                ("snapshot_seconds", C.c_double), ("recoveries", C.c_uint64), ("recovered", C.c_uint32), ("merge_finalize", C.c_uint32)]
 
 
 # every entry point declared in include/f2v.h: name -> (restype, argtypes)

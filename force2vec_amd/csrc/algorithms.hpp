@@ -185,10 +185,13 @@ class algorithms {
             // the snapshot, "recover" = 0) the handle has already switched to launches without in-grid waits, and the run is
             // repeated here from its seed -- same process, same bytes as a healthy run.
             const int64_t before = param("recoveries");
+            const bool waits_before = param("merge_finalize") != 0;
             const bool repeatable = seeded;
             seeded = false;
             int rc = f2v_train(h, option, IT, B, ns, lr, bs, &gpu_train_seconds);
-            if (rc == F2V_ESTATE && repeatable && param("merge_finalize") == 0) {
+            // (a lost launch is the one failure that switches "merge_finalize" from 1 to 0; any other F2V_ESTATE -- and a handle
+            // whose in-grid waits the caller had switched off -- is reported, not retried)
+            if (rc == F2V_ESTATE && repeatable && waits_before && param("merge_finalize") == 0) {
                 std::cerr << "Force2Vec: " << f2v_last_error() << "\nForce2Vec: running again from seed " << last_seed << std::endl;
                 check(f2v_srand(h, last_seed));
                 init(math);

@@ -110,6 +110,12 @@ struct f2v_ctx {
     // f2v_train survives a give-up ("recover"): the matrix and the rand() state as they were when the call began
     bool recover = true;
     float *d_snap = nullptr;
+    hipEvent_t ev_snap[2] = {nullptr, nullptr};  // around the snapshot copy: f2v_stats.snapshot_seconds
+    // in-grid waits that were switched off by a RECOVERED give-up come back by themselves: after `waits_backoff` healthy f2v_train
+    // calls (1, then 2, 4 ... 64: a card that keeps losing launches is asked less and less often); a give-up that was not recovered
+    // from, the dispatch probe's verdict and the caller's own "merge_finalize" = 0 stay
+    bool waits_suspended = false;
+    uint32_t waits_backoff = 1, calls_since_give_up = 0;
     uint32_t recoveries = 0;
     bool unit_degi = false;  // the option being run is 10 (StepArgs::unit_degi): set by every entry point that takes an option
     uint32_t mark_every = 0;       // "epoch_marks"
@@ -509,7 +515,9 @@ const Plan &plan_for(f2v_ctx *c, uint32_t row_lo, uint32_t row_hi, bool walk) {
 
 // Minibatches per chained launch ("chain_rows" rows per launch, at most 4096 minibatches)
 uint32_t chain_len(const f2v_ctx *c, uint32_t batch, bool wide_form = false) {
-    const uint64_t k = (uint64_t)(wide_form ? c->wide_rows : c->chain_rows) / std::max(batch, 1u);
+    uint64_t k = (uint64_t)(wide_form ? c->wide_rows : c->chain_rows) / std::max(batch, 1u);
+    // handed-on rows are read through a buffer resource that starts at the launch's first row, at 32-bit byte offsets (load16_agent)
+    k = std::min<uint64_t>(k, 0xFFFFFFFFull / ((uint64_t)std::max(batch, 1u) * c->D * sizeof(float)));
     return (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(k, 1));
 }
 
@@ -970,7 +978,8 @@ const WidePlan &wide_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t batc
         if (c->count_compulsory) p.compulsory += compulsory_bytes(c, lo, hi, walk, nnz, mb_items);
     }
     p.n_slots = slots;
-    if (slots > kItemSlotMask) c->plan_overflow = true;
+    // (the helpers' group sums are imported at 32-bit byte offsets: load16_agent)
+    if (slots > kItemSlotMask || (uint64_t)slots * c->D * sizeof(float) > 0xFFFFFFFFull) c->plan_overflow = true;
     c->max_slots = std::max<size_t>(c->max_slots, slots);
     return c->wides.emplace(key, p).first->second;
 }
@@ -980,7 +989,7 @@ int upload_plans(f2v_ctx *c) {
     if (c->plan_overflow) {
         c->plan_overflow = false;
         drop_plans(c);
-        return fail(F2V_EINVAL, "a launch plan needs more than 2^28 partial-sum slots: use a larger \"hub_chunk\" or fewer \"chain_rows\"");
+        return fail(F2V_EINVAL, "a launch plan needs more than 2^28 partial-sum slots (or, in the wide form, 4 GiB of them): use a larger \"hub_chunk\" or fewer \"chain_rows\" / \"wide_rows\"");
     }
     const size_t need_slots = c->max_slots;
     const bool grow_items = c->h_items.size() > c->d_items_cap, grow_hubs = c->h_hubs.size() > c->d_hubs_cap;
@@ -1384,6 +1393,7 @@ int launch_chain(f2v_ctx *c, int math, const ChainPlan &plan, const uint32_t *d_
 #undef F2V_C
 #undef F2V_C2
     HIPC(hipGetLastError());
+    c->last_train_form = 1;
     if (c->upd_hi == c->upd_lo) c->upd_lo = plan.lo;
     c->upd_hi = plan.hi;
     c->pending = true;
@@ -1499,6 +1509,8 @@ int launch_wide(f2v_ctx *c, int math, const WidePlan &plan, const uint32_t *d_id
     // "wide_samples_early" (-1 = automatic): on for graphs of up to 2 M nonzeros, whose launches are one dependency chain
     const bool early = ring || (c->wide_samples_early >= 0 ? c->wide_samples_early != 0 : c->nnz <= (2ull << 20));
     c->last_wide_early = early;
+    c->last_wide_width = width;
+    c->last_train_form = 2;
     c->last_wide_epochs = std::max(c->last_wide_epochs, epochs);  // (the most epochs one launch of this f2v_train has carried)
     const uint32_t grid = plan.n_wgs * epochs;
 #define F2V_W3(OPT, LPI, NB, U, FULL, MODE) hipLaunchKernelGGL((qwide_chain_kernel<OPT, LPI, NB, U, FULL, MODE>), dim3(grid), dim3(256), 0, c->stream, wa)
@@ -1814,6 +1826,8 @@ int f2v_destroy(f2v_handle c) {
     if (c->d_stamps) (void)hipFree(c->d_stamps);
 #endif
     if (c->h_kerr) (void)hipHostFree(c->h_kerr);
+    for (hipEvent_t e : c->ev_snap)
+        if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return F2V_OK;
@@ -2018,6 +2032,7 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
     }
     if (!strcmp(name, "merge_finalize")) {
         c->merge_fin = value != 0;
+        c->waits_suspended = false;  // the caller's own choice stands
         return F2V_OK;
     }
     if (!strcmp(name, "chain_batches")) {
@@ -2108,6 +2123,12 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
     }
     if (!strcmp(name, "recover")) {
         c->recover = value != 0;
+        if (!c->recover && c->d_snap) {  // the snapshot matrix goes with the net
+            HIPC(hipSetDevice(c->device));
+            HIPC(hipStreamSynchronize(c->stream));
+            (void)hipFree(c->d_snap);
+            c->d_snap = nullptr;
+        }
         return F2V_OK;
     }
     if (!strcmp(name, "push_landing")) {  // takes effect at the next f2v_push_export
@@ -2373,6 +2394,8 @@ int f2v_stream(f2v_handle c, uint64_t *out) {
 int f2v_get_stats(f2v_handle c, f2v_stats *out) {
     if (!c || !out) return fail(F2V_EINVAL, "null argument");
     *out = c->stats;
+    out->recoveries = c->recoveries;
+    out->merge_finalize = c->merge_fin ? 1u : 0u;
     return F2V_OK;
 }
 
@@ -2388,6 +2411,11 @@ int f2v_train(f2v_handle c, int option, uint32_t iters, uint32_t batch, uint32_t
     bool snap = false;
     Rand rng0 = c->rng;
     const uint64_t fast_epoch0 = c->fast_epoch;
+    if (c->waits_suspended && !c->merge_fin && ++c->calls_since_give_up > c->waits_backoff) {
+        c->merge_fin = true;  // a recovered give-up is taken for a transient: the fast launch forms come back (with the net below)
+        c->waits_suspended = false;
+    }
+    double snap_seconds = 0.0;
     if (c->recover && c->merge_fin && c->have_x && iters > 0) {  // (merge_fin: this handle's launches may hold in-grid waits)
         HIPC(hipSetDevice(c->device));
         int rc = flush_pending(c);
@@ -2398,11 +2426,22 @@ int f2v_train(f2v_handle c, int option, uint32_t iters, uint32_t batch, uint32_t
             c->d_snap = nullptr;
         }
         if (c->d_snap) {
+            for (auto &e : c->ev_snap)
+                if (!e) HIPC(hipEventCreateWithFlags(&e, hipEventDefault));
+            HIPC(hipEventRecord(c->ev_snap[0], c->stream));
             HIPC(hipMemcpyAsync(c->d_snap, c->d_X[c->cur], bytes, hipMemcpyDeviceToDevice, c->stream));
+            HIPC(hipEventRecord(c->ev_snap[1], c->stream));
             snap = true;
         }
     }
+    const bool waits_before = c->merge_fin;
     int rc = train_impl(c, option, iters, batch, ns, lr, bs_mode, seconds_out, false);
+    if (snap && hipEventQuery(c->ev_snap[1]) == hipSuccess) {  // (train_impl has synchronised the stream on every healthy way out)
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev_snap[0], c->ev_snap[1]) == hipSuccess) snap_seconds = ms * 1e-3;
+    }
+    (void)hipGetLastError();
+    bool recovered = false;
     if (rc == F2V_ESTATE && snap && c->x_invalid && !c->merge_fin) {
         const std::string why = f2v_last_error();
         HIPC(hipStreamSynchronize(c->stream));
@@ -2413,8 +2452,18 @@ int f2v_train(f2v_handle c, int option, uint32_t iters, uint32_t batch, uint32_t
         c->x_invalid = false;
         c->recoveries++;
         rc = train_impl(c, option, iters, batch, ns, lr, bs_mode, seconds_out, false);
-        if (rc == F2V_OK) (void)fail(F2V_OK, "f2v_train recovered: the call was run again from its start with one launch per minibatch and tree level after: %s", why.c_str());
+        if (rc == F2V_OK) {
+            recovered = true;
+            (void)fail(F2V_OK, "f2v_train recovered: the call was run again from its start with one launch per minibatch and tree level after: %s", why.c_str());
+            if (waits_before) {  // in-grid waits come back after a few healthy calls (doubling: 1, 2, 4 ... 64)
+                c->waits_suspended = true;
+                c->calls_since_give_up = 0;
+                c->waits_backoff = c->recoveries <= 1 ? 1u : std::min(c->waits_backoff * 2u, 64u);
+            }
+        }
     }
+    c->stats.snapshot_seconds = snap_seconds;
+    c->stats.recovered = recovered ? 1u : 0u;
     return rc;
 }
 
@@ -2481,10 +2530,10 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
     ) {
         epochs_max = c->wide_epochs ? c->wide_epochs : (c->nnz <= (2ull << 20) ? 32u : 1u);
         epochs_max = (uint32_t)std::min<uint64_t>(epochs_max, (8ull << 30) / std::max<uint64_t>((uint64_t)n * c->D * sizeof(float), 1));  // the ring stays below 8 GiB
+        if (2ull * n * c->D * sizeof(float) > 0xFFFFFFFFull) epochs_max = 1;  // an epoch's two matrices of the ring are read at 32-bit byte offsets (load16_agent)
     }
     c->last_wide_epochs = 1;
-    c->last_train_form = wide ? 2 : chained ? 1 : 0;
-    if (wide) c->last_wide_width = wide_width(c, batch);
+    c->last_train_form = 0;  // (set where a launch is made: launch_step 0 / 3 under hipGraph replay, launch_chain 1, launch_wide 2)
     if (wide) {
         for (uint32_t b0 = 0; b0 < nb; b0 += K) (void)wide_plan_for(c, b0, std::min(K, nb - b0), batch, math == 7);
     } else if (chained) {
@@ -2497,7 +2546,10 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
         }
     }
     if ((rc = upload_plans(c)) != F2V_OK) return rc;
-    const uint64_t dev_ids = std::max<uint64_t>(all_upfront ? per_epoch * std::max(iters, 1u) : per_epoch, 64);
+    // (epochs whose ids cannot all be drawn up-front alternate between two device buffers: reserved HERE, once -- a second, larger
+    // reservation further down would hipFree the first, and hipFree waits for every stream of the device: with the ranks of a push
+    // exchange as engines of ONE process (tools/push_world_local.py) that is a peer's spinning barrier kernel, which waits for this rank)
+    const uint64_t dev_ids = std::max<uint64_t>(all_upfront ? per_epoch * std::max(iters, 1u) : 2 * per_epoch, 64);
     if ((rc = reserve_ids(c, dev_ids)) != F2V_OK) return rc;
     c->ids_valid = 0;
     std::vector<uint32_t> ids;
@@ -2565,6 +2617,7 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
     // stream-ordered, and looked at without blocking as soon as the copy has run: a lost run fails within an epoch or two
     // of the give-up instead of at its very end.  Four copies may be in flight (ring of events / 64-byte slots of h_kerr).
     constexpr int kErrRing = 4;
+    uint32_t err_seq = 0;
     hipEvent_t err_ev[kErrRing];
     bool err_used[kErrRing] = {};
     for (auto &e : err_ev)
@@ -2581,6 +2634,7 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
     };
     const bool graphed = c->use_graph && math != 7 && all_upfront && iters >= 2 && !sharded;
     if (graphed) {
+        c->last_train_form = 3;  // one launch per minibatch and tree level, replayed from two captured graphs
         // hipGraph replay: an epoch's launch chain is identical every epoch except for (a) which of the two matrices
         // is read and which written -- they alternate, hence one graph per epoch parity -- and (b) the sample ids,
         // which each replay finds at a fixed place (its parity's region of d_ids), refreshed by a stream-ordered copy.
@@ -2765,7 +2819,7 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
             mark_ev.push_back(e);
         }
         if (c->merge_fin) {
-            const int slot = (int)(it % kErrRing);
+            const int slot = (int)(err_seq++ % kErrRing);  // (by copies made, not by epoch: a launch may carry 32 epochs)
             const uint32_t *bad = poll_errors(err_used[slot], slot);  // the slot about to be reused is waited for (4 epochs old)
             if (!bad) {
                 HIPC(hipMemcpyAsync(c->h_kerr + 16 * slot, c->d_kerr, 64, hipMemcpyDeviceToHost, c->stream));

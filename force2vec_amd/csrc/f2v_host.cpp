@@ -252,7 +252,7 @@ using namespace f2v;
 extern "C" {
 
 const char *f2v_last_error(void) { return g_err; }
-const char *f2v_version(void) { return "f2v-mi355x 0.4 (gfx950)"; }
+const char *f2v_version(void) { return "f2v-mi355x 0.5 (gfx950)"; }
 
 f2v_rng *f2v_rng_create(uint32_t seed) {
     Rand *g = new Rand();
@@ -477,7 +477,8 @@ int f2v_read_embd(const char *path, uint32_t *n_out, uint32_t *dim_out, float **
     FILE *fp = fopen(path, "rb");
     if (!fp) return fail(F2V_EIO, "f2v_read_embd: cannot open %s: %s", path, strerror(errno));
     unsigned long long n = 0, dim = 0;
-    if (fscanf(fp, "%llu %llu", &n, &dim) != 2 || n == 0 || dim == 0 || n > 0xFFFFFFFFull || dim > 512) {
+    // (no bound on D beyond the header's own fields: the reference's writeToFile has none, and the engine's generic kernel takes any D)
+    if (fscanf(fp, "%llu %llu", &n, &dim) != 2 || n == 0 || dim == 0 || n > 0xFFFFFFFFull || dim > 0xFFFFFFFFull || n > (~(size_t)0) / sizeof(float) / dim) {
         fclose(fp);
         return fail(F2V_EIO, "f2v_read_embd: %s does not start with '<N> <D>'", path);
     }
@@ -495,7 +496,14 @@ int f2v_read_embd(const char *path, uint32_t *n_out, uint32_t *dim_out, float **
         }
         seen[id - 1] = 1;
     }
+    // nothing but white space may follow the N-th row: a longer file is not the N x D matrix its header announces
+    int ch;
+    while ((ch = fgetc(fp)) != EOF && (ch == ' ' || ch == '\t' || ch == '\n' || ch == '\r')) {}
     fclose(fp);
+    if (ch != EOF) {
+        free(x);
+        return fail(F2V_EIO, "f2v_read_embd: %s holds more than the %llu rows its header announces", path, n);
+    }
     *n_out = (uint32_t)n;
     *dim_out = (uint32_t)dim;
     *x_out = x;

@@ -45,6 +45,12 @@
 #include <stdint.h>
 
 namespace f2v {
+#ifdef F2V_TEST_HOOKS
+// The self-test build (libf2v_selftest.so) has a StepArgs of its own (four more fields) and kernels that read it: they are types
+// and symbols of their own, so that no loader, however the two libraries meet in one process, can pair one build's launch stub
+// or argument block with the other's kernel.
+inline namespace selftest {
+#endif
 
 // One unit of work: a whole row, or one chunk of a hub row's neighbour list.
 struct Item {
@@ -777,16 +783,40 @@ __device__ __forceinline__ const float *row_src(const StepArgs &a, uint32_t j, u
     return ((j - a.upd_lo) < a.upd_rows ? a.Xn : a.X) + (size_t)j * D;
 }
 
-// 16 bytes of a row that another workgroup of THIS launch has written (written through, sc1) and announced: loaded at agent
-// scope (global_load_dwordx2 sc1 twice: past the L1, which no store of another CU ever refreshes) -- the measured hand-off
-// recipe of MI355X_MICROARCH.md: sc1 stores, the storing wave's vmcnt(0), sc1 flag store, sc1 poll, and EVERY load of the
-// handed-off bytes an sc1 load.  Only rows of the launch's own earlier minibatches (~2 % of the gathers) are read this way.
-__device__ __forceinline__ float4 load16_agent(const float *p) {
-    const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p);
-    const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return make_float4(__builtin_bit_cast(float, (uint32_t)lo), __builtin_bit_cast(float, (uint32_t)(lo >> 32)),
-                       __builtin_bit_cast(float, (uint32_t)hi), __builtin_bit_cast(float, (uint32_t)(hi >> 32)));
+// 16 bytes of a row that another workgroup of THIS launch has written (written through, sc1) and announced: ONE 16-byte load at
+// agent scope (buffer_load_dwordx4 ... sc1: past the L1, which no store of another CU ever refreshes) -- the measured hand-off
+// recipe of MI355X_MICROARCH.md (table row 1: sc1 stores, the storing wave's vmcnt(0), sc1 flag store, sc1 poll, and EVERY load
+// of the handed-off bytes a global_/buffer_ sc1 load of 4, 8 or 16 bytes).  __hip_atomic_load stops at 64 bits -- rounds 2-3 read
+// such rows as two global_load_dwordx2 sc1, which the guide prices at 0.54-0.70x the 16-byte rate -- so the load is the raw
+// buffer form (the compiler tracks it in vmcnt like any other load; an inline-asm global_load would need hand-kept counters).
+// The buffer resource must be wave-uniform while an item's row is not: the resource spans everything a launch can hand on, and
+// the row is a 32-bit byte offset (the host keeps every such span below 4 GiB: chain_len, epochs_max, wide_plan_for).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t hand_rsrc(const float *base) {
+    // raw buffer: stride 0, no range check (num_records = 2^32 - 1), gfx9 dword 3 with DATA_FORMAT = 32 bits
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ float4 load16_agent(rsrc_t r, uint32_t byte_off) {
+    // (bit_cast of the builtin's own vector type: initialising an ext_vector int4 from it compiles to a ONE-dword load + splat)
+    const f32x4_t v = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, /*aux: sc1*/ 16));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+// Where the rows a launch hands on live: row j of the second matrix (written by an earlier minibatch of the launch) at byte
+// xn_off + j * row_bytes of `r`, row j of the first matrix (a launch that chains epochs: written by its previous epoch) at x_off + ...
+// -- uint32 arithmetic, wrapping: xn_off is "minus the launch's first row" where the resource starts at that row.
+struct HandSrc {
+    rsrc_t r;
+    uint32_t xn_off, x_off, row_bytes;
+    __device__ __forceinline__ uint32_t at(uint32_t j, bool second) const { return j * row_bytes + (second ? xn_off : x_off); }
+};
+// one launch of minibatches [chain_lo, ...) over the two matrices: handed rows are rows of the second matrix from chain_lo on
+__device__ __forceinline__ HandSrc hand_src_window(const StepArgs &a, uint32_t D) {
+    HandSrc h;
+    h.r = hand_rsrc(a.Xn + (size_t)a.chain_lo * D);
+    h.row_bytes = D * 4u;
+    h.xn_off = 0u - a.chain_lo * h.row_bytes;
+    h.x_off = 0u;  // (unused: nothing of the first matrix is handed on)
+    return h;
 }
 
 // One item's list of row ids; `cnt` is this item's length, `maxcnt` the wave's (uniform).
@@ -795,7 +825,7 @@ __device__ __forceinline__ float4 load16_agent(const float *p) {
 // FULL: D == 4*LPI*NB.  Otherwise D is any smaller multiple of 4 (rows stay 16-byte aligned): lane t's block b is live
 // iff 4*LPI*b + 4t < D, dead pieces read as zero -- the zero padding of the canonical tree -- and are never stored.
 template <int OPT, int LPI, int NB, bool NEG, int U, bool FULL, bool CHAIN>
-__device__ __forceinline__ void qprocess(const StepArgs &a, const uint32_t *ids, uint32_t cnt, uint32_t maxcnt, uint32_t t, uint32_t D,
+__device__ __forceinline__ void qprocess(const StepArgs &a, const HandSrc &hs, const uint32_t *ids, uint32_t cnt, uint32_t maxcnt, uint32_t t, uint32_t D,
                                          const float (&xi)[NB][4], float (&Y)[NB][4], double c0, const float *table, bool &bad) {
     uint32_t j[U];
 #pragma unroll
@@ -814,7 +844,7 @@ __device__ __forceinline__ void qprocess(const StepArgs &a, const uint32_t *ids,
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
                     if (!(FULL || 4u * LPI * b + 4u * t < D)) xj[u][b] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    else if (CHAIN && handed) xj[u][b] = load16_agent(src + 4 * LPI * b);
+                    else if (CHAIN && handed) xj[u][b] = load16_agent(hs.r, hs.at(j[u], true) + 16u * t + 16u * LPI * b);
                     else xj[u][b] = *reinterpret_cast<const float4 *>(src + 4 * LPI * b);
                 }
             }
@@ -835,7 +865,7 @@ __device__ __forceinline__ void qprocess(const StepArgs &a, const uint32_t *ids,
 // `between` runs once per call, when the list's first gathers are out and before anything is waited for (all threads of the
 // workgroup reach it: it may hold a barrier; -> true: the workgroup gives up).
 template <int OPT, int LPI, int NB, int U, bool FULL, class Between>
-__device__ __forceinline__ void qprocess_pre(const StepArgs &a, const uint32_t *ids, uint32_t cnt, uint32_t maxcnt, uint32_t t, uint32_t D,
+__device__ __forceinline__ void qprocess_pre(const StepArgs &a, const HandSrc &hs, const uint32_t *ids, uint32_t cnt, uint32_t maxcnt, uint32_t t, uint32_t D,
                                              const float (&xi)[NB][4], float (&Y)[NB][4], double c0, const float *table, bool &bad,
                                              uint32_t (&j)[U], const uint32_t *next_ids, uint32_t next_cnt, Between &&between,
                                              const uint32_t *prev_flags) {
@@ -881,14 +911,14 @@ __device__ __forceinline__ void qprocess_pre(const StepArgs &a, const uint32_t *
             for (int u = 0; u < U; ++u) {
                 if (handed[u] && fl[u] == a.seq) {
                     asm volatile("" ::: "memory");  // the row's loads stay behind the poll
-                    const float *src = (inr[u] ? a.Xn : a.X) + (size_t)j0[u] * D + t * 4;
+                    const uint32_t off = hs.at(j0[u], inr[u]) + 16u * t;
 #pragma unroll
                     for (int b = 0; b < NB; ++b) {
                         if (!(FULL || 4u * LPI * b + 4u * t < D)) xj[u][b] = make_float4(0.f, 0.f, 0.f, 0.f);
 #ifdef F2V_TEST_HOOKS
-                        else if (a.test_nowait & 4u) xj[u][b] = *reinterpret_cast<const float4 *>(src + 4 * LPI * b);
+                        else if (a.test_nowait & 4u) xj[u][b] = *reinterpret_cast<const float4 *>((inr[u] ? a.Xn : a.X) + (size_t)j0[u] * D + t * 4 + 4 * LPI * b);
 #endif
-                        else xj[u][b] = load16_agent(src + 4 * LPI * b);
+                        else xj[u][b] = load16_agent(hs.r, off + 16u * LPI * b);
                     }
                     handed[u] = false;
                 }
@@ -910,11 +940,11 @@ __device__ __forceinline__ void qprocess_pre(const StepArgs &a, const uint32_t *
             for (int u = 0; u < U; ++u) {
                 if (handed[u] && fl[u] == a.seq) {
                     asm volatile("" ::: "memory");
-                    const float *src = (inr[u] ? a.Xn : a.X) + (size_t)j0[u] * D + t * 4;
+                    const uint32_t off = hs.at(j0[u], inr[u]) + 16u * t;
 #pragma unroll
                     for (int b = 0; b < NB; ++b) {
                         if (!(FULL || 4u * LPI * b + 4u * t < D)) xj[u][b] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        else xj[u][b] = load16_agent(src + 4 * LPI * b);
+                        else xj[u][b] = load16_agent(hs.r, off + 16u * LPI * b);
                     }
                     handed[u] = false;
                 }
@@ -932,14 +962,14 @@ __device__ __forceinline__ void qprocess_pre(const StepArgs &a, const uint32_t *
             if (handed[u]) {
                 if (fl[u] != a.seq) bad = wait_row_at(a, inr[u] ? a.rowflag : prev_flags, j0[u]) || bad;  // its flag, then agent-scope loads
                 asm volatile("" ::: "memory");
-                const float *src = (inr[u] ? a.Xn : a.X) + (size_t)j0[u] * D + t * 4;
+                const uint32_t off = hs.at(j0[u], inr[u]) + 16u * t;
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
                     if (!(FULL || 4u * LPI * b + 4u * t < D)) xj[u][b] = make_float4(0.f, 0.f, 0.f, 0.f);
 #ifdef F2V_TEST_HOOKS
-                    else if (a.test_nowait & 4u) xj[u][b] = *reinterpret_cast<const float4 *>(src + 4 * LPI * b);
+                    else if (a.test_nowait & 4u) xj[u][b] = *reinterpret_cast<const float4 *>((inr[u] ? a.Xn : a.X) + (size_t)j0[u] * D + t * 4 + 4 * LPI * b);
 #endif
-                    else xj[u][b] = load16_agent(src + 4 * LPI * b);
+                    else xj[u][b] = load16_agent(hs.r, off + 16u * LPI * b);
                 }
                 cf[u] = pair_coef_q<OPT, LPI, NB, false>(xi, xj[u], a.lr, c0, table);
             }
@@ -996,6 +1026,7 @@ __device__ __forceinline__ void qstep_body(const StepArgs &a, const uint32_t blk
     constexpr uint32_t kLdsSamples = 8;
     __shared__ float4 smp[kLdsSamples][DP / 4];
     const bool lds_samples = !a.bs_mode && a.ns <= kLdsSamples;
+    const HandSrc hs = hand_src_window(a, D);  // (chained launches: where handed-on rows are read, 16 bytes at agent scope)
     // options 6/7: the 8-KiB sigmoid table is looked up once per interaction, in the middle of the dependent chain
     // dot product -> sigma -> update; from LDS that lookup costs ~64 cycles instead of an L1/L2 round trip
     __shared__ float sm_lds[OPT == 5 ? 1 : 2048];
@@ -1014,7 +1045,7 @@ __device__ __forceinline__ void qstep_body(const StepArgs &a, const uint32_t blk
             }
             const float *srow = row_src(a, a.sample_ids[sidx], D);
             smp[sidx][c4] = !(FULL || 4u * c4 < D) ? make_float4(0.f, 0.f, 0.f, 0.f)
-                            : (CHAIN && handed)    ? load16_agent(srow + 4 * c4)
+                            : (CHAIN && handed)    ? load16_agent(hs.r, hs.at(a.sample_ids[sidx], true) + 16u * c4)
                                                    : reinterpret_cast<const float4 *>(srow)[c4];
         }
     }
@@ -1064,7 +1095,7 @@ __device__ __forceinline__ void qstep_body(const StepArgs &a, const uint32_t blk
     }
 
     bool bad = false;  // chained minibatches: a wait for an earlier minibatch's row gave up -- this item stores nothing
-    qprocess<OPT, LPI, NB, false, U, FULL, CHAIN>(a, a.nbr_ids + it.nb, it.cnt, wave_max_of_items<LPI>(it.cnt), t, D, xi, Y, c0, table, bad);
+    qprocess<OPT, LPI, NB, false, U, FULL, CHAIN>(a, hs, a.nbr_ids + it.nb, it.cnt, wave_max_of_items<LPI>(it.cnt), t, D, xi, Y, c0, table, bad);
     if (lds_samples) {
         if (active && last_chunk) {
             for (uint32_t sidx = 0; sidx < a.ns; ++sidx) {
@@ -1077,7 +1108,7 @@ __device__ __forceinline__ void qstep_body(const StepArgs &a, const uint32_t blk
     } else {
         const uint32_t scnt = (active && last_chunk) ? a.ns : 0u;
         const uint32_t sbase = a.bs_mode ? (row - a.batch_lo) : 0u;
-        qprocess<OPT, LPI, NB, true, U, FULL, CHAIN>(a, a.sample_ids + sbase, scnt, wave_max_of_items<LPI>(scnt), t, D, xi, Y, c0, table, bad);
+        qprocess<OPT, LPI, NB, true, U, FULL, CHAIN>(a, hs, a.sample_ids + sbase, scnt, wave_max_of_items<LPI>(scnt), t, D, xi, Y, c0, table, bad);
     }
 
     if (CHAIN && __builtin_amdgcn_ballot_w64(bad) != 0ull) {
@@ -1309,6 +1340,15 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (MODE == 2 ? 2 : OPT == 
     const uint32_t D = FULL ? DP : a.D;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t t = lane & (LPI - 1u), q = lane / LPI;
+    // where handed-on rows are read (16 bytes at agent scope): the launch's window of the second matrix, or -- epochs chained
+    // in one launch -- this epoch's two matrices of the ring, which lie ring_stride floats apart
+    HandSrc hs = hand_src_window(a, D);
+    if (EPOCHS && w.wgs_per_epoch != 0u) {
+        hs.r = hand_rsrc(a.X);
+        hs.x_off = 0u;
+        hs.xn_off = (uint32_t)(w.ring_stride * 4u);
+    }
+    const rsrc_t part_rsrc = hand_rsrc(a.partials);  // helpers' group sums (partial-sum slot s at byte s * 4D)
     if (bd.kind == 1u) {
         constexpr int FVEC = DP >= 64u ? (int)(DP / 64u) : 1;
         FinalizeTreeArgs ft;
@@ -1368,7 +1408,7 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (MODE == 2 ? 2 : OPT == 
                 smp[sidx][c4] = make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
                 bad = wait_row_at(a, (sj - a.chain_lo) < a.chain_rows ? a.rowflag : prev_flags, sj) || bad;
-                smp[sidx][c4] = load16_agent(row_src(a, sj, D) + 4 * c4);
+                smp[sidx][c4] = load16_agent(hs.r, hs.at(sj, (sj - a.chain_lo) < a.chain_rows) + 16u * c4);
             }
         }
         return bad;
@@ -1441,7 +1481,7 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (MODE == 2 ? 2 : OPT == 
                     }
                     return acc;
                 };
-                if (d < D) {  // (D is a multiple of 32 in chained launches: a wavefront's quads are live or idle as a whole)
+                if (d < D) {  // (D is a multiple of 4 wherever the sub-wave layouts run -- subwave_width() -- so the quads that gather16<1> regroups below are live or idle as a whole)
                     float xi1 = 0.f;
                     if (OPT == 5 && jb.kind == kJobRow) {
                         // (a launch that chains epochs: the row's pieces in this workgroup have waited for its previous value already)
@@ -1517,8 +1557,7 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (MODE == 2 ? 2 : OPT == 
                     if (gave_up) {
                         wg_bad = 1u;
                     } else {
-                        const float *src = a.partials + (size_t)jb.row * D;
-                        for (uint32_t c = tl; 4u * c < D; c += 32u) slots[jb.dst][c] = load16_agent(src + 4u * c);
+                        for (uint32_t c = tl; 4u * c < D; c += 32u) slots[jb.dst][c] = load16_agent(part_rsrc, jb.row * (D * 4u) + 16u * c);
                     }
                 } else {
                     // slots [first, first + n) added in order, 8 LDS reads in flight
@@ -1537,7 +1576,7 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (MODE == 2 ? 2 : OPT == 
                     };
                     for (uint32_t c = tl; 4u * c < D; c += 32u) {
                         float4 xi4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (OPT == 5 && jb.kind == kJobRow) xi4 = prev_flags != nullptr ? load16_agent(a.X + (size_t)jb.row * D + 4u * c) : *reinterpret_cast<const float4 *>(a.X + (size_t)jb.row * D + 4u * c);
+                        if (OPT == 5 && jb.kind == kJobRow) xi4 = prev_flags != nullptr ? load16_agent(hs.r, hs.at(jb.row, false) + 16u * c) : *reinterpret_cast<const float4 *>(a.X + (size_t)jb.row * D + 4u * c);
 #ifdef F2V_TEST_HOOKS
                         const bool skip_sums = (a.test_nowait & 8u) != 0u;
 #else
@@ -1608,7 +1647,7 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (MODE == 2 ? 2 : OPT == 
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (FULL || 4u * LPI * b + 4u * t < D) v = prev_flags != nullptr ? load16_agent(src + 4 * LPI * b) : *reinterpret_cast<const float4 *>(src + 4 * LPI * b);
+                if (FULL || 4u * LPI * b + 4u * t < D) v = prev_flags != nullptr ? load16_agent(hs.r, hs.at(row, false) + 16u * t + 16u * LPI * b) : *reinterpret_cast<const float4 *>(src + 4 * LPI * b);
                 xi[b][0] = v.x; xi[b][1] = v.y; xi[b][2] = v.z; xi[b][3] = v.w;
             }
         }
@@ -1661,7 +1700,7 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (MODE == 2 ? 2 : OPT == 
             }
             return false;
         };
-        qprocess_pre<OPT, LPI, NB, U, FULL>(a, a.nbr_ids + it.nb, cnt, wave_max_of_items<LPI>(cnt), t, D, xi, Y, c0, table, bad, jpre,
+        qprocess_pre<OPT, LPI, NB, U, FULL>(a, hs, a.nbr_ids + it.nb, cnt, wave_max_of_items<LPI>(cnt), t, D, xi, Y, c0, table, bad, jpre,
                                             a.nbr_ids + itn.nb, (itn.flags & kItemIdle) ? 0u : itn.cnt, between, prev_flags);
         if constexpr (!EARLY) (void)stage_late();
         if (quit) return;
@@ -1689,7 +1728,7 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (MODE == 2 ? 2 : OPT == 
         } else {
             const uint32_t scnt = (!idle && last_chunk) ? a.ns : 0u;
             const uint32_t sbase = a.bs_mode ? (row - a.batch_lo) : 0u;
-            qprocess<OPT, LPI, NB, true, U, FULL, true>(a, a.sample_ids + sbase, scnt, wave_max_of_items<LPI>(scnt), t, D, xi, Y, c0, table, bad);
+            qprocess<OPT, LPI, NB, true, U, FULL, true>(a, hs, a.sample_ids + sbase, scnt, wave_max_of_items<LPI>(scnt), t, D, xi, Y, c0, table, bad);
         }
         const bool wave_bad = __builtin_amdgcn_ballot_w64(bad) != 0ull;  // (wave-uniform: a wave stores all its items or none)
         if (wave_bad) wg_bad = 1u;
@@ -2032,5 +2071,8 @@ __global__ void wave_reduce_test_kernel(const float *in, uint32_t rows, uint32_t
 }
 #endif  // F2V_TEST_HOOKS
 
+#ifdef F2V_TEST_HOOKS
+}  // inline namespace selftest
+#endif
 }  // namespace f2v
 #endif

@@ -23,6 +23,13 @@
 extern "C" {
 #endif
 
+/* The ABI: libf2v.so is built with -fvisibility=hidden -Wl,-Bsymbolic and exports exactly the functions marked F2V_API
+ * (tests/test_host_boundary.py checks `nm -D`).  Nothing else -- no kernel launch stub, no C++ helper -- can be interposed by,
+ * or interpose on, another library of the process (two builds of libf2v in one process are two independent engines). */
+#ifndef F2V_API
+#define F2V_API __attribute__((visibility("default")))
+#endif
+
 #define F2V_OK 0
 #define F2V_EINVAL (-1)  /* bad argument */
 #define F2V_ENODEV (-2)  /* no usable HIP device / HIP runtime error */
@@ -35,25 +42,25 @@ extern "C" {
 
 typedef struct f2v_ctx *f2v_handle;
 
-const char *f2v_last_error(void);
-const char *f2v_version(void);
+F2V_API const char *f2v_last_error(void);
+F2V_API const char *f2v_version(void);
 
 /* ---- engine life cycle -----------------------------------------------------------------
  * Replaces `algorithms::algorithms(CSR&, input, outputdir, dim, gamma, batch)`
  * (sample/algorithms.h:60-70): copies the CSR (rowptr u32[n+1], colids u32[nnz], ascending
  * inside each row, duplicates kept -- sample/CSR.h:89-96) to HBM and allocates the N x D
  * fp32 embedding matrix there.  `device` is the HIP device ordinal. */
-int f2v_create(const uint32_t *rowptr, const uint32_t *colids, uint32_t n, uint64_t nnz, uint32_t dim, int device,
+F2V_API int f2v_create(const uint32_t *rowptr, const uint32_t *colids, uint32_t n, uint64_t nnz, uint32_t dim, int device,
                f2v_handle *out);
-int f2v_destroy(f2v_handle h);
+F2V_API int f2v_destroy(f2v_handle h);
 
 /* srand(seed) of Test/Force2Vec.cpp:126; the handle carries the libc rand() stream. */
-int f2v_srand(f2v_handle h, uint32_t seed);
+F2V_API int f2v_srand(f2v_handle h, uint32_t seed);
 /* randInitF / randInit (sample/algorithms.cpp:38-53): N*D rand() draws, uploaded to HBM. */
-int f2v_init_embeddings(f2v_handle h, int kind);
+F2V_API int f2v_init_embeddings(f2v_handle h, int kind);
 /* Direct access to the embedding matrix `nCoordinates` (sample/algorithms.h:55), host N x D row-major. */
-int f2v_set_embeddings(f2v_handle h, const float *x);
-int f2v_get_embeddings(f2v_handle h, float *x_out);
+F2V_API int f2v_set_embeddings(f2v_handle h, const float *x);
+F2V_API int f2v_get_embeddings(f2v_handle h, float *x_out);
 
 /* Tunables.  "hub_chunk": neighbours per work item before a row is split (0 = never split: the
  * reference's summation order for every row; unset = chosen by f2v_train from the rows one launch covers
@@ -97,8 +104,8 @@ int f2v_get_embeddings(f2v_handle h, float *x_out);
  * the reference's libc rand() stream); negative-sample ids still come from the handle's rand() stream.
  * f2v_get_param also answers "dim", "n", "nnz", "hub_chunk_auto" (1 while the chunk is still chosen per call), and for
  * a handle attached to a push exchange "push_rank", "push_world", "shared_card" (1: a peer runs on this very GPU). */
-int f2v_set_param(f2v_handle h, const char *name, int64_t value);
-int f2v_get_param(f2v_handle h, const char *name, int64_t *value_out);
+F2V_API int f2v_set_param(f2v_handle h, const char *name, int64_t value);
+F2V_API int f2v_get_param(f2v_handle h, const char *name, int64_t *value_out);
 
 /* ---- training --------------------------------------------------------------------------
  * Replaces vector<float> algorithms::AlgoForce2VecNS / NSBS / NSRW / NSRWBS / NSRWEFF and
@@ -110,7 +117,7 @@ int f2v_get_param(f2v_handle h, const char *name, int64_t *value_out);
  * CLI's "-bs" (1 = ns*batch samples per minibatch, row i uses samples [i, i+ns)).
  * seconds_out (may be NULL) receives the device time of the epoch loop alone (HIP events);
  * the embeddings stay in HBM (fetch with f2v_get_embeddings). */
-int f2v_train(f2v_handle h, int option, uint32_t iters, uint32_t batch, uint32_t ns, float lr, int bs_mode,
+F2V_API int f2v_train(f2v_handle h, int option, uint32_t iters, uint32_t batch, uint32_t ns, float lr, int bs_mode,
               double *seconds_out);
 /* (While "recover" is on -- the default -- and the handle uses in-grid waits, f2v_train keeps a copy of the matrix and of the
  * rand() state as they were when the call began: one more N x D matrix of HBM, one device-to-device copy per call.  A call
@@ -125,44 +132,44 @@ int f2v_train(f2v_handle h, int option, uint32_t iters, uint32_t batch, uint32_t
  * ranks' rows of the same minibatch are merged first with f2v_stage_write / an all-gather).  sample_ids: host array of the minibatch's
  * negative-sample vertex ids (ns of them, or (batch_hi-batch_lo)+ns-1 in bs_mode).
  * Option 7 uses the walks set by f2v_set_walks. */
-int f2v_minibatch_step(f2v_handle h, int option, uint32_t batch_lo, uint32_t batch_hi, uint32_t row_lo,
+F2V_API int f2v_minibatch_step(f2v_handle h, int option, uint32_t batch_lo, uint32_t batch_hi, uint32_t row_lo,
                        uint32_t row_hi, const uint32_t *sample_ids, uint32_t n_sample_ids, uint32_t ns, float lr,
                        int bs_mode);
 /* The same step with the sample ids already in HBM: f2v_upload_sample_ids copies a host array (e.g. one
  * epoch's ids, drawn up-front: they do not depend on the embeddings) once, f2v_minibatch_step_at names the
  * minibatch's ids by their offset in it.  No host-device synchronisation per step: the multi-GPU driver
  * enqueues step and exchange back to back. */
-int f2v_upload_sample_ids(f2v_handle h, const uint32_t *ids, uint64_t count);
-int f2v_minibatch_step_at(f2v_handle h, int option, uint32_t batch_lo, uint32_t batch_hi, uint32_t row_lo,
+F2V_API int f2v_upload_sample_ids(f2v_handle h, const uint32_t *ids, uint64_t count);
+F2V_API int f2v_minibatch_step_at(f2v_handle h, int option, uint32_t batch_lo, uint32_t batch_hi, uint32_t row_lo,
                           uint32_t row_hi, uint64_t ids_offset, uint32_t ns, float lr, int bs_mode);
 /* Commit the staged minibatch into the matrix (K5, sample/algorithms.cpp:629-639 / 913-921). */
-int f2v_flush(f2v_handle h);
+F2V_API int f2v_flush(f2v_handle h);
 /* Option 7 walk samples of the current epoch, uint32[5*n] (sample/algorithms.cpp:1097-1118). */
-int f2v_set_walks(f2v_handle h, const uint32_t *walks);
+F2V_API int f2v_set_walks(f2v_handle h, const uint32_t *walks);
 /* Draw this epoch's walks from the handle's rand() stream exactly as the reference does. */
-int f2v_generate_walks(f2v_handle h, uint32_t *walks_out /* may be NULL */);
+F2V_API int f2v_generate_walks(f2v_handle h, uint32_t *walks_out /* may be NULL */);
 /* randIndex(max,min) of sample/algorithms.cpp:55-58 on the handle's stream. */
-int f2v_rand_index(f2v_handle h, uint32_t max_num, uint32_t min_num, uint32_t *out);
+F2V_API int f2v_rand_index(f2v_handle h, uint32_t max_num, uint32_t min_num, uint32_t *out);
 /* `count` consecutive randIndex(max,min) draws; the first `keep` (<= count) are stored in out.
  * (One minibatch's sample loop, sample/algorithms.cpp:577-586; -bs 1 draws ns*BATCH, :686.) */
-int f2v_rand_indices(f2v_handle h, uint32_t max_num, uint32_t min_num, uint64_t count, uint64_t keep, uint32_t *out);
+F2V_API int f2v_rand_indices(f2v_handle h, uint32_t max_num, uint32_t min_num, uint64_t count, uint64_t keep, uint32_t *out);
 
 /* Multi-GPU exchange: device address of the staged rows of the last stepped minibatch (row r of the
  * batch at float offset (r-batch_lo)*dim; it points into the second matrix), the number of rows that may
  * be written from there (the matrix has slack behind row N for a padded all-gather), and a host
  * read/write of a row range of it (gloo / test path). */
-int f2v_stage_device_ptr(f2v_handle h, uint64_t *devptr_out, uint32_t *capacity_rows_out);
-int f2v_stage_read(f2v_handle h, uint32_t row_lo, uint32_t row_hi, float *out);
-int f2v_stage_write(f2v_handle h, uint32_t row_lo, uint32_t row_hi, const float *in);
-int f2v_stage_reserve(f2v_handle h, uint32_t rows);
+F2V_API int f2v_stage_device_ptr(f2v_handle h, uint64_t *devptr_out, uint32_t *capacity_rows_out);
+F2V_API int f2v_stage_read(f2v_handle h, uint32_t row_lo, uint32_t row_hi, float *out);
+F2V_API int f2v_stage_write(f2v_handle h, uint32_t row_lo, uint32_t row_hi, const float *in);
+F2V_API int f2v_stage_reserve(f2v_handle h, uint32_t rows);
 /* Arbitrary rows of the matrix the staged rows live in (the epoch's second matrix), by vertex id: the
  * per-destination exchange ("send a row only to the ranks that read it") packs and unpacks with these. */
-int f2v_rows_read(f2v_handle h, const uint32_t *ids, uint32_t count, float *out);
-int f2v_rows_write(f2v_handle h, const uint32_t *ids, uint32_t count, const float *in);
+F2V_API int f2v_rows_read(f2v_handle h, const uint32_t *ids, uint32_t count, float *out);
+F2V_API int f2v_rows_write(f2v_handle h, const uint32_t *ids, uint32_t count, const float *in);
 /* Device address of the embedding matrix and the HIP stream (as integers) for zero-copy wrapping. */
-int f2v_embeddings_device_ptr(f2v_handle h, uint64_t *devptr_out);
-int f2v_stream(f2v_handle h, uint64_t *stream_out);
-int f2v_synchronize(f2v_handle h);
+F2V_API int f2v_embeddings_device_ptr(f2v_handle h, uint64_t *devptr_out);
+F2V_API int f2v_stream(f2v_handle h, uint64_t *stream_out);
+F2V_API int f2v_synchronize(f2v_handle h);
 
 /* ---- multi-GPU: the push exchange over xGMI -----------------------------------------------
  * One process per GPU, the graph and both matrices replicated, rank r computes the r-th contiguous slice
@@ -192,23 +199,23 @@ int f2v_synchronize(f2v_handle h);
  * (Fault injection for the protocol tests lives in the self-test build only: include/f2v_test.h.) */
 #define F2V_PUSH_MAX_RANKS 8
 #define F2V_PUSH_EXPORT_BYTES 256
-int f2v_push_export(f2v_handle h, void *handles_out);
-int f2v_push_attach(f2v_handle h, uint32_t rank, uint32_t world, const void *all_handles);
-int f2v_push_selftest(f2v_handle h);
-int f2v_push_detach(f2v_handle h);
-int f2v_train_sharded(f2v_handle h, int option, uint32_t iters, uint32_t batch, uint32_t ns, float lr, int bs_mode,
+F2V_API int f2v_push_export(f2v_handle h, void *handles_out);
+F2V_API int f2v_push_attach(f2v_handle h, uint32_t rank, uint32_t world, const void *all_handles);
+F2V_API int f2v_push_selftest(f2v_handle h);
+F2V_API int f2v_push_detach(f2v_handle h);
+F2V_API int f2v_train_sharded(f2v_handle h, int option, uint32_t iters, uint32_t batch, uint32_t ns, float lr, int bs_mode,
                       double *seconds_out);
 /* Host-only: the slices f2v_train_sharded cuts minibatch [lo,hi) into: bounds_out[0..world], slice r = rows
  * [bounds_out[r], bounds_out[r+1]), contiguous and balanced by work (weight of a row = its degree + 4), not by
  * row count.  (Option 7 uses equal row counts: its rows all have five pairs.) */
-int f2v_shard_bounds(const uint32_t *rowptr, uint32_t lo, uint32_t hi, uint32_t world, uint32_t *bounds_out);
+F2V_API int f2v_shard_bounds(const uint32_t *rowptr, uint32_t lo, uint32_t hi, uint32_t world, uint32_t *bounds_out);
 /* Host-only: masks_out[v] = bit r set when rank r READS row v without owning it -- v is a CSR neighbour of a
  * row in one of r's slices (f2v_shard_bounds of every minibatch), or one of `sample_ids` (read by every row of a
  * minibatch, hence by every rank). */
-int f2v_push_masks(const uint32_t *rowptr, const uint32_t *colids, uint32_t n, uint32_t batch, uint32_t world,
+F2V_API int f2v_push_masks(const uint32_t *rowptr, const uint32_t *colids, uint32_t n, uint32_t batch, uint32_t world,
                    const uint32_t *sample_ids, uint64_t n_ids, uint32_t *masks_out);
 /* Rows pushed to peers / rows a full all-gather would have sent (per peer copies), since the last f2v_train_sharded began. */
-int f2v_push_stats(f2v_handle h, uint64_t *rows_pushed_out, uint64_t *rows_allgather_out);
+F2V_API int f2v_push_stats(f2v_handle h, uint64_t *rows_pushed_out, uint64_t *rows_allgather_out);
 
 /* Statistics of the last f2v_train: launches of the step kernel, rows and nonzeros they
  * processed, algorithmic bytes (SURVEY 8d formula), device seconds. */
@@ -225,72 +232,82 @@ typedef struct {
      * numerator of a roofline fraction that cannot exceed 1 (the SURVEY 8d figure above charges every neighbour row to
      * HBM and does, on power-law graphs whose hub rows are cache hits). */
     uint64_t compulsory_bytes;
+    /* (library 0.5) f2v_train keeps a snapshot of the matrix while "recover" is on and the handle's launches may hold in-grid waits:
+     * one device-to-device copy of N x D floats per CALL, on the stream in front of the epoch loop and NOT part of device_seconds /
+     * seconds_out -- its own device time is reported here (a caller that trains one epoch per call pays it every epoch: RMAT-20
+     * ~0.2 ms, RMAT-24 ~3 ms; "recover" = 0 drops the copy and frees the matrix). */
+    double snapshot_seconds;
+    uint64_t recoveries;      /* give-ups f2v_train has recovered from since the handle was created ("recoveries") */
+    uint32_t recovered;       /* 1: the LAST f2v_train lost a launch and ran again without in-grid waits: its device_seconds are those of
+                               * the slow launch forms -- a benchmark must not quote them as the fast path's */
+    uint32_t merge_finalize;  /* the handle's "merge_finalize" now: 0 after a give-up = one launch per minibatch and tree level until the
+                               * in-grid waits come back (after 1, 2, 4 ... 64 healthy f2v_train calls) */
 } f2v_stats;
-int f2v_get_stats(f2v_handle h, f2v_stats *out);
+F2V_API int f2v_get_stats(f2v_handle h, f2v_stats *out);
 /* With "epoch_marks" = k > 0 the next f2v_train records a HIP event on its stream after every k-th epoch (at most 4096 of
  * them); afterwards f2v_train_marks copies the device time from the start of the epoch loop to each mark into `seconds_out`
  * (up to `cap` values; `count_out` receives how many there are): the rate over a long run second by second, without a host
  * synchronisation inside the loop. */
-int f2v_train_marks(f2v_handle h, double *seconds_out, uint32_t cap, uint32_t *count_out);
+F2V_API int f2v_train_marks(f2v_handle h, double *seconds_out, uint32_t cap, uint32_t *count_out);
 
 /* ---- host-side I/O of the drop-in boundary (no device needed) ----------------------------
  * f2v_read_mtx replaces SetInputMatricesAsCSR (sample/commonutility.h:44-54 -> ReadASCII
  * sample/IO.h:59-156, CSC sample/CSC.h:146-188, CSR sample/CSR.h:154-186): MatrixMarket
  * coordinate text; "symmetric" mirrors off-diagonal entries and drops self-loops;
  * duplicates kept; colids ascending per row.  Arrays are malloc'ed; free with f2v_free. */
-int f2v_read_mtx(const char *path, uint32_t *n_out, uint64_t *nnz_out, uint32_t **rowptr_out, uint32_t **colids_out);
-void f2v_free(void *p);
+F2V_API int f2v_read_mtx(const char *path, uint32_t *n_out, uint64_t *nnz_out, uint32_t **rowptr_out, uint32_t **colids_out);
+F2V_API void f2v_free(void *p);
 /* Replaces algorithms::writeToFile (sample/algorithms.h:118-136): "<N> <D>\n", then
  * "<i+1> v0 v1 ... \n" with 6 significant digits (%g) and a trailing space. */
-int f2v_write_embd(const char *path, const float *x, uint32_t n, uint32_t dim);
+F2V_API int f2v_write_embd(const char *path, const float *x, uint32_t n, uint32_t dim);
 /* Output file name rule of writeToFile + the per-option suffixes (sample/algorithms.cpp:650,
  * 752, 930, 1059, 1201, 1635, 2047, 2409, 2860): outdir + basename(input) + suffix + ".embd". */
-int f2v_output_name(const char *input, const char *outdir, int option, int bs_mode, uint32_t batch, uint32_t dim,
+F2V_API int f2v_output_name(const char *input, const char *outdir, int option, int bs_mode, uint32_t batch, uint32_t dim,
                     uint32_t iters, uint32_t ns, char *out, size_t out_len);
 
 /* SURVEY 8f "next" rows on the data-format side of the path.
  * Binary CSR cache (text parsing of 10^8-edge files dominates wall time otherwise): little-endian
  * "F2VCSR1\0", u32 n, u32 reserved, u64 nnz, u32 rowptr[n+1], u32 colids[nnz] -- exactly the arrays
  * f2v_read_mtx returns, so a cached graph trains bit-identically. */
-int f2v_write_csr_bin(const char *path, const uint32_t *rowptr, const uint32_t *colids, uint32_t n, uint64_t nnz);
-int f2v_read_csr_bin(const char *path, uint32_t *n_out, uint64_t *nnz_out, uint32_t **rowptr_out, uint32_t **colids_out);
+F2V_API int f2v_write_csr_bin(const char *path, const uint32_t *rowptr, const uint32_t *colids, uint32_t n, uint64_t nnz);
+F2V_API int f2v_read_csr_bin(const char *path, uint32_t *n_out, uint64_t *nnz_out, uint32_t **rowptr_out, uint32_t **colids_out);
 /* Raw fp32 N x D embedding file, the format the reference's scorers read with readBinEmbeddings
  * (performancescores/runnodeclassclust.py:81-100); text .embd of 16 M x 128 values is ~19 GB. */
-int f2v_write_embd_bin(const char *path, const float *x, uint32_t n, uint32_t dim);
+F2V_API int f2v_write_embd_bin(const char *path, const float *x, uint32_t n, uint32_t dim);
 /* The readers of both embedding formats (what performancescores/runnodeclassclust.py:57-100 reads): warm starts
  * (f2v_set_embeddings; `Force2Vec -init <file>`) and scoring without the text round trip.  f2v_read_embd allocates *x_out (N x D
  * floats, release with f2v_free); rows may come in any order, ids are 1-based. */
-int f2v_read_embd(const char *path, uint32_t *n_out, uint32_t *dim_out, float **x_out);
-int f2v_read_embd_bin(const char *path, uint32_t n, uint32_t dim, float *x_out);
+F2V_API int f2v_read_embd(const char *path, uint32_t *n_out, uint32_t *dim_out, float **x_out);
+F2V_API int f2v_read_embd_bin(const char *path, uint32_t n, uint32_t dim, float *x_out);
 
 /* Stand-alone libc rand() stream (glibc TYPE_3), for hosts that pre-draw sample ids. */
 typedef struct f2v_rng f2v_rng;
-f2v_rng *f2v_rng_create(uint32_t seed);
-void f2v_rng_destroy(f2v_rng *g);
-int f2v_rng_next(f2v_rng *g);
+F2V_API f2v_rng *f2v_rng_create(uint32_t seed);
+F2V_API void f2v_rng_destroy(f2v_rng *g);
+F2V_API int f2v_rng_next(f2v_rng *g);
 /* Skip k draws in O(log k) (the generator is linear: a 31x31 matrix over Z/2^32 per jump). */
-void f2v_rng_jump(f2v_rng *g, uint64_t k);
+F2V_API void f2v_rng_jump(f2v_rng *g, uint64_t k);
 /* `count` values as randInitF (kind 0) / randInit (kind 1) would store them, drawn from ONE serial stream but filled
  * in parallel from jump-ahead states; the stream ends where `count` serial draws would leave it. */
-int f2v_rng_fill(f2v_rng *g, float *out, uint64_t count, int kind);
+F2V_API int f2v_rng_fill(f2v_rng *g, float *out, uint64_t count, int kind);
 
 /* One epoch's option-7 walk samples uint32[5*n] from stream g, exactly the reference's draws in the reference's order
  * (sample/algorithms.cpp:1097-1118) -- what f2v_generate_walks does with the handle's own stream, without a device. */
-int f2v_rng_walks(f2v_rng *g, const uint32_t *rowptr, const uint32_t *colids, uint32_t n, uint64_t nnz, uint32_t *walks_out);
+F2V_API int f2v_rng_walks(f2v_rng *g, const uint32_t *rowptr, const uint32_t *colids, uint32_t n, uint64_t nnz, uint32_t *walks_out);
 
 /* The 2048-entry sigmoid table of init_SM_TABLE (sample/algorithms.cpp:757-764) as the source defines it. */
-int f2v_sm_table(float *table_out /* 2048 */);
+F2V_API int f2v_sm_table(float *table_out /* 2048 */);
 
 /* ---- diagnostics (bench.py, tools/ipc_preflight.py, bin/Force2Vec -gpus) ------------------ */
 /* Rehearsal of the push exchange's needs (IPC mapping of `bytes` of device memory and of fine-grained flags between
  * `world` processes that meet through files in `dir`, remote stores from a kernel), for a throw-away process to run
  * before the real engines exist: a mapping call that never returns or a faulting remote store then costs only it. */
-int f2v_diag_ipc_preflight(int device, uint32_t rank, uint32_t world, const char *dir, uint64_t bytes, double timeout_s);
+F2V_API int f2v_diag_ipc_preflight(int device, uint32_t rank, uint32_t world, const char *dir, uint64_t bytes, double timeout_s);
 /* On-box streaming-copy ceiling: read + written bytes per second (GB/s) of a 16-byte-per-lane copy of `bytes`, best of `reps`. */
-int f2v_diag_stream_copy(int device, uint64_t bytes, uint32_t reps, double *gbps_out);
+F2V_API int f2v_diag_stream_copy(int device, uint64_t bytes, uint32_t reps, double *gbps_out);
 /* On-box random-row gather ceiling (GB/s, ids included): every 512-byte row of a `table_bytes` table fetched once per pass
  * in random order with the step kernel's access pattern.  32 MiB: the Infinity Cache / L2 rate; 4 GiB: the HBM rate. */
-int f2v_diag_gather_rate(int device, uint64_t table_bytes, uint32_t reps, double *gbps_out);
+F2V_API int f2v_diag_gather_rate(int device, uint64_t table_bytes, uint32_t reps, double *gbps_out);
 
 #ifdef __cplusplus
 }

@@ -17,35 +17,35 @@ extern "C" {
 #endif
 
 /* Runs the wavefront tree reduction on `rows` rows of `width` (<=512) floats; out[r] = sum. */
-int f2v_test_wave_reduce(int device, const float *in, uint32_t rows, uint32_t width, float *out);
+F2V_API int f2v_test_wave_reduce(int device, const float *in, uint32_t rows, uint32_t width, float *out);
 /* The push exchange between engines of ONE process on one device (direct pointers instead of HIP IPC; every
  * engine is driven by its own host thread): runs the push kernels, masks and flag barriers under a profiler. */
-int f2v_test_push_attach_local(f2v_handle h, uint32_t rank, uint32_t world, const f2v_handle *all);
+F2V_API int f2v_test_push_attach_local(f2v_handle h, uint32_t rank, uint32_t world, const f2v_handle *all);
 /* PMC calibration: `reps` launches that each gather `rows` distinct 512-byte rows exactly once with
  * the step kernel's access pattern (known HBM read volume rows*516 bytes per launch). */
-int f2v_test_gather_calibration(int device, uint32_t rows, uint32_t reps);
+F2V_API int f2v_test_gather_calibration(int device, uint32_t rows, uint32_t reps);
 /* Fault injection for the one-launch minibatch: the hub piece that owns partial-sum slot `slot` never announces its
  * sum (0xFFFFFFFF: none), so the combine-tree node that adds it has to give up its wait ("tree_timeout_ms"). */
-int f2v_test_withhold_flag(f2v_handle h, uint32_t slot);
+F2V_API int f2v_test_withhold_flag(f2v_handle h, uint32_t slot);
 /* Fault injection for chained launches: the flag of `row` is never stored (0xFFFFFFFF: none), so every item of a later
  * minibatch of the same launch that reads the row has to give up its wait ("chain_timeout_ms"). */
-int f2v_test_withhold_row(f2v_handle h, uint32_t row);
+F2V_API int f2v_test_withhold_row(f2v_handle h, uint32_t row);
 /* Timing experiment: chained launches skip their row waits (the results are then WRONG): what the launch structure costs
  * without the dependency chain. */
-int f2v_test_chain_nowait(f2v_handle h, int on);
+F2V_API int f2v_test_chain_nowait(f2v_handle h, int on);
 
 /* Where a chained launch spends its time: with `on`, chained launches record per row four words of the 100-MHz device wall
  * clock -- [0] when its last hub piece announced its partial sum, [1] when its last inner combine-tree node did, [2] when its
  * row flag was stored, [3] the bitwise complement of the first time a waiter that had to wait saw that flag.  `out` (4*n words,
  * may be null) receives what has been recorded so far; the words are cleared whenever `on` is set.  tools/chain_hops.py. */
-int f2v_test_stamps(f2v_handle h, int on, unsigned long long *out);
+F2V_API int f2v_test_stamps(f2v_handle h, int on, unsigned long long *out);
 
 /* Host-only (no device): builds the wide form's launch plans of one epoch for this graph, batch and tunables (`names` / `values`:
  * hub_chunk, hub_fanin, class_cut, wide_phases, wide_rounds, wide_span, wide_finish, wide_order, wide_rows, wide_min_width) and
  * checks what the kernel relies on: every row finished once, every neighbour in one piece, rounds / phases / slots / passes
  * well-formed, a job adds consecutive pieces of one row, and every wait (an imported group sum, a tree node's inputs) points at a
  * workgroup with a SMALLER index.  stats_out[6]: workgroups, helpers, finishers, packed, node workgroups, partial-sum slots. */
-int f2v_test_wide_plan_check(const uint32_t *rowptr, const uint32_t *colids, uint32_t n, uint64_t nnz, uint32_t dim, uint32_t batch, int walk,
+F2V_API int f2v_test_wide_plan_check(const uint32_t *rowptr, const uint32_t *colids, uint32_t n, uint64_t nnz, uint32_t dim, uint32_t batch, int walk,
                              const char *const *names, const int64_t *values, uint32_t n_params, uint64_t *stats_out);
 
 #ifdef __cplusplus

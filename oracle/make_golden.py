@@ -11,6 +11,7 @@ libc rand() after srand(1).
 
 Usage: python oracle/make_golden.py      (from the repo root, in the build container)
        python oracle/make_golden.py --avx512-only   (only the "avx512_cases" / option-11 F1 sections, manifest updated in place)
+       python oracle/make_golden.py --longrun-only  (only the F1 tables of the reference's options 6 / 7 at 300 epochs and the 100-epoch option-5 rows)
 
 Options 8-11 (the AVX512 twins, oracle/_ref/Force2Vec_avx512): per case the md5 of the text and a sample of it -- the whole
 text for karate, every 8th row parsed to fp32 for cora -- against which the oracle (CPU test) and the HIP path (GPU test) are
@@ -118,8 +119,45 @@ def avx512_sections(manifest):
     print(manifest["f1_reference_cora_opt11_it1200_B256_D128"])
 
 
+def longrun_sections(manifest):
+    """Reference-tied long-horizon gates (round 4): node-classification F1 tables of the reference's OWN options 6 and 7 on cora after
+    300 epochs (the manifest's md5-pinned runs; same seeded splits as every other table), and every 8th row of the reference's scalar
+    option-5 output after 100 epochs (md5-pinned case cora_opt5_it100_B256_D128_bs0) for the divergence curve of BASELINE.md."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import f1_harness as H
+    labels = H.load_labels(os.path.join(REF_INPUT, "cora.nodes.labels"), 2708)
+    pinned = {c["name"]: c for c in manifest["cases"]}
+    for option in (6, 7):
+        with tempfile.TemporaryDirectory() as td:
+            path, _ = O.run_reference(os.path.join(REF_INPUT, "cora.mtx"), td, option, 300, 256, 128, threads=1)
+            md5 = hashlib.md5(open(path, "rb").read()).hexdigest()
+            assert md5 == pinned["cora_opt%d_it300_B256_D128_bs0" % option]["md5"], "the reference run differs from the manifest's pinned md5"
+            f1 = H.f1_scores(O.read_embd(path), labels)
+            key = "f1_reference_cora_opt%d_it300_B256_D128" % option
+            manifest[key] = {"%.2f" % k: {"micro": v[0], "macro": v[1]} for k, v in f1.items()}
+            manifest[key]["md5"] = md5
+            print(key, manifest[key])
+    with tempfile.TemporaryDirectory() as td:
+        path, _ = O.run_reference(os.path.join(REF_INPUT, "cora.mtx"), td, 5, 100, 256, 128, threads=1)
+        md5 = hashlib.md5(open(path, "rb").read()).hexdigest()
+        assert md5 == pinned["cora_opt5_it100_B256_D128_bs0"]["md5"], "the reference run differs from the manifest's pinned md5"
+        X = O.read_embd(path)
+        name = "cora_opt5_it100_B256_D128_bs0.rows.f32.gz"
+        with gzip.GzipFile(os.path.join(GOLD, name), "wb", mtime=0) as f:
+            f.write(np.ascontiguousarray(X[::8], dtype="<f4").tobytes())
+        manifest["rows_reference_cora_opt5_it100_B256_D128"] = {"file": name, "row_stride": 8, "md5": md5, "iters": 100, "batch": 256, "dim": 128, "option": 5}
+        print(name, md5)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if "--longrun-only" in sys.argv:
+        with open(os.path.join(GOLD, "manifest.json")) as f:
+            manifest = json.load(f)
+        longrun_sections(manifest)
+        with open(os.path.join(GOLD, "manifest.json"), "w") as f:
+            json.dump(manifest, f, indent=1)
+        return
     if "--avx512-only" in sys.argv:
         with open(os.path.join(GOLD, "manifest.json")) as f:
             manifest = json.load(f)
@@ -169,6 +207,7 @@ def main():
         v = libc.rand()
     manifest["rand_1000000th"] = v
     avx512_sections(manifest)
+    longrun_sections(manifest)
     with open(os.path.join(GOLD, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1)
 

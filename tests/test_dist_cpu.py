@@ -49,6 +49,9 @@ def _ids(cases):
 
 # world 3 (ragged and empty shards) on the small cases only: every spawn costs seconds
 PAIRS = [(c, 2) for c in CASES] + [(c, 3) for c in CASES[:4]]
+# world 8 = F2V_PUSH_MAX_RANKS, what the driver's scaling run uses: 16-row minibatches of karate (2 rows per rank, a 2-row tail: six
+# empty slices), 5-row minibatches (three empty slices in every minibatch, option 7), cora (32-row slices, a 148-row tail)
+PAIRS += [(CASES[0], 8), (CASES[3], 8), (CASES[5], 8)]
 
 
 @pytest.mark.parametrize("case,world", PAIRS, ids=["%s-w%d" % (i, w) for i, (c, w) in zip(_ids([p[0] for p in PAIRS]), PAIRS)])

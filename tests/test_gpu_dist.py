@@ -286,6 +286,31 @@ def test_rccl_in_place_all_gather_on_engine_stream(exchange, tmp_path):
     assert np.array_equal(np.load(str(tmp_path / "r0.npy")), _single(case))
 
 
+def test_push_exchange_at_world_8_in_one_process():
+    """World 8 = F2V_PUSH_MAX_RANKS (the driver's scaling run) had never executed anywhere: kMaxRanks peer tables, reader-mask bit 7,
+    the 8-lane xgmi_barrier_kernel, pushes into 7 peers.  A GPU box admits at most 6 processes on its card, so the rehearsal runs 8
+    ENGINES in one process (self-test build, peers attached by direct pointers, one host thread and one stream per rank):
+    tools/push_world_local.py -- cora option 5, pubmed option 6, karate option 7 with 5-row minibatches (empty slices), cora option
+    11 at D = 100 through landing buffers with the separate push kernel; every replica bit-identical to the single-engine run."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "push_world_local.py"), "8"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("replicas identical to the single engine: all 8") == 4, r.stdout
+
+
+def test_push_exchange_at_world_5_through_ipc(tmp_path):
+    """The most ranks-as-processes one card of this pool takes (6 GPU processes, the test runner being one): every rank attaches
+    FOUR peers through hipIpcOpenMemHandle; bit-identical on every rank."""
+    import torch.multiprocessing as mp
+    case = ("cora.mtx", 5, 3, 256, 128, 0)
+    mp.spawn(_gloo_worker, args=(5, _free_port(), case, str(tmp_path), "push"), nprocs=5, join=True)
+    want = _single_twice(case)
+    for r in range(5):
+        assert np.array_equal(np.load(str(tmp_path / ("r%d.npy" % r))), want)
+
+
 def test_bench_launches_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` with no launcher around it: bench.py starts torch.distributed.run itself as a child process
     (before it has touched the GPU), relays rank 0's JSON line as its ONLY stdout line and returns the ranks' exit code.

@@ -41,6 +41,23 @@ def test_abi_exports_every_declared_symbol():
         assert hasattr(T, name), name
 
 
+def test_dynamic_symbol_table_is_the_abi_and_nothing_else():
+    """libf2v.so is linked with hidden visibility, -Bsymbolic and a version script (Makefile: LIBFLAGS): its dynamic symbol table
+    is exactly include/f2v.h, the self-test build's exactly f2v.h + f2v_test.h.  Round 3 exported 465 more -- among them every
+    kernel's host-side handle variable, weak: two builds of the library in one process then shared ONE handle address for two
+    different code objects (the `address 0x1000` GPU fault of the CLI under LD_PRELOAD=libf2v_selftest.so)."""
+    def exported(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        return {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert exported(_lib.LIB_PATH) == _declared("f2v.h")
+    assert exported(_lib.SELFTEST_LIB_PATH) == _declared("f2v.h") | _declared("f2v_test.h")
+    # the two builds' kernels are different symbols altogether (inline namespace f2v::selftest): no stub or handle can be shared
+    names = subprocess.run(["nm", "-C", _lib.SELFTEST_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "f2v::selftest::qstep_kernel<" in names and "f2v::qstep_kernel<" not in names.replace("f2v::selftest::", "")
+    names = subprocess.run(["nm", "-C", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "f2v::qstep_kernel<" in names and "f2v::selftest::" not in names
+
+
 def test_no_cpu_fallback():
     rp, ci = F.read_mtx(golden_graph_path("karate.mtx"))
     try:
@@ -191,6 +208,14 @@ def test_embedding_readers_round_trip(tmp_path):
     open(txt, "w").write("\n".join([lines[0], lines[1], lines[1]] + lines[3:]) + "\n")  # a row twice
     with pytest.raises(F.F2VError):
         F.read_embd(txt)
+    open(txt, "w").write("\n".join(lines) + "\n\n  \n")                                # trailing white space is not content ...
+    assert np.array_equal(F.read_embd(txt), got)
+    open(txt, "w").write("\n".join(lines + [lines[1]]) + "\n")                          # ... a row beyond the announced N is
+    with pytest.raises(F.F2VError):
+        F.read_embd(txt)
+    wide = rng.uniform(-1, 1, (3, 700)).astype(np.float32)                              # the reference's writeToFile has no bound on D
+    F.write_embd(txt, wide)
+    assert F.read_embd(txt).shape == (3, 700) and np.abs(F.read_embd(txt) - wide).max() < 5e-6
 
 
 def test_header_is_plain_c_and_links(tmp_path):

@@ -11,7 +11,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 chained = 0
 for k in range(cases):
     scale, ef = int(rng.integers(9, 15)), int(rng.integers(2, 25))
-    dim = int(rng.choice([16, 32, 48, 64, 96, 128, 256]))
+    dim = int(rng.choice([16, 20, 32, 48, 64, 96, 100, 128, 256]))
     option = int(rng.choice([5, 6]))
     n = 1 << scale
     batch = int(rng.choice([32, 64, 96, 128, 256, 384, 512, 1000, 2048]))

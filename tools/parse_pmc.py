@@ -67,7 +67,8 @@ def main():
         cal[where] = c
     factor = cal["hbm"]["known_bytes_per_launch"] / (cal["hbm"]["FETCH_SIZE"] * 1024.0)
     l2_miss = step["FETCH_SIZE"] * 1024.0 * factor + step["WRITE_SIZE"] * 1024.0
-    res = {"batch": batch, "scale": scale, "dim": dim, "option": option,
+    import time
+    res = {"batch": batch, "scale": scale, "dim": dim, "option": option, "collected": time.strftime("%Y-%m-%d"),
            "hub_chunk": (bench_line.get("config") or {}).get("hub_chunk"), "kernel": (bench_line.get("roofline") or {}).get("kernel"),
            "library": None,
            "l2_miss_bytes_per_launch": l2_miss,
