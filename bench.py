@@ -700,8 +700,9 @@ def main():
                               "counted by the engine) / average launch time; frac <= 1 by construction",
                 # SURVEY 8d's count charges EVERY neighbour row to HBM: a rate of useful bytes delivered to the CUs, served by L2 + Infinity Cache + HBM together
                 "algorithmic_bytes_per_launch": alg, "algorithmic_GBs": alg / t_launch * 1e-9,
-                "algorithmic_frac_note": "SURVEY 8d bytes / launch time / peak = %.2f: > 1 on a power-law graph because cache-served re-reads of hub rows are charged to HBM -- "
-                                         "a delivery rate of useful bytes (L2 + Infinity Cache + HBM together), not a fraction of the HBM roofline" % (alg / t_launch * 1e-9 / HBM_PEAK_GBS,)}
+                "algorithmic_frac_note": ("SURVEY 8d bytes / launch time / peak = %.2f%s: every neighbour row is charged to HBM there although re-reads of hub rows are served by "
+                                          "the caches -- a delivery rate of useful bytes (L2 + Infinity Cache + HBM together), not a fraction of the HBM roofline")
+                                         % (alg / t_launch * 1e-9 / HBM_PEAK_GBS, " (> 1)" if alg / t_launch * 1e-9 > HBM_PEAK_GBS else "")}
         live = None
         if not use_dist and args.live_pmc > 0:
             note(rank, "roofline.traffic: rocprofv3 --pmc passes over a child run of the same workload (at most %d s)" % args.live_pmc)

@@ -20,6 +20,7 @@
 #include <mutex>
 #include <memory>
 #include <string>
+#include <atomic>
 #include <thread>
 #include <tuple>
 #include <type_traits>
@@ -53,6 +54,11 @@ struct Plan {
     uint32_t fin_cnt[kMaxFinLevels] = {};
     uint64_t nnz = 0;
     uint64_t compulsory = 0;  // bytes this launch must move even with perfect caching inside the launch ("count_compulsory")
+};
+
+struct SeenScratch {  // "count_compulsory": has this row been counted in this minibatch?  One stamp per vertex (a plan-building thread owns one)
+    std::vector<uint32_t> seen;
+    uint32_t stamp = 0;
 };
 
 // One launch of qstep_chain_kernel: up to 64 consecutive minibatches (f2v_kernels.hip.h, "chained minibatches")
@@ -123,7 +129,7 @@ struct f2v_ctx {
     uint32_t last_wide_width = 0;  // the layout width of the last wide-form f2v_train ("last_wide_width")
     bool last_wide_early = false;  // ... and whether it ran the kernel's EARLY form ("last_wide_early")
     int last_train_form = 0;  // how the last f2v_train launched: 0 one launch per minibatch, 1 chained, 2 chained in the wide form ("last_train_form")
-    bool plan_overflow = false;  // a launch plan needed more than 2^28 partial-sum slots (kItemSlotMask)
+    bool plan_overflow = false;  // a launch plan needed more than 2^27 partial-sum slots (kItemSlotMask)
     uint32_t *h_kerr = nullptr;  // pinned: the kernel error words as of the last completed epoch-end copy (train_impl)
 #ifdef F2V_TEST_HOOKS
     uint32_t test_withhold_slot = kNoSlot, test_withhold_row = kNoSlot;
@@ -167,6 +173,10 @@ struct f2v_ctx {
     uint32_t ring_epochs = 0;   // epochs the ring buffers are sized for
     bool ring_refused = false;  // the device had no room for them
     size_t ring_slots = 0;      // partial-sum slots per epoch they are sized for
+    // "wide_single" (measurement only): the wide form also where a launch holds ONE minibatch -- nothing is handed on inside such a
+    // launch, what is left of the form is "a split row's pieces meet in LDS" (no partial sums through HBM, no tree nodes below
+    // fanin^2 pieces): the plain launch form's alternative for large minibatches, measured and rejected (profiles/r04_*)
+    bool wide_single = false;
     int wide_samples_early = -1;  // "wide_samples_early": StepArgs::samples_early; -1 = automatic (graphs of up to 2 M nonzeros: the launch is one dependency chain)
     uint32_t wide_rounds = 0;   // rounds per phase of such a workgroup (0: one for minibatches of up to 512 rows, else as many as fill the piece slots)
     uint32_t wide_span = 2;     // fan-in groups per helper workgroup
@@ -192,8 +202,7 @@ struct f2v_ctx {
     bool piece_affinity = true;    // hub pieces are placed on the XCD that owns their neighbours' id range (see plan_for)
     bool shared_card = false;      // a peer of the push exchange runs on the same GPU: placement goes back to same-XCD groups
     bool count_compulsory = false;  // plans also count their compulsory bytes (f2v_stats.compulsory_bytes; costs O(nnz) per new plan)
-    std::vector<uint32_t> seen_stamp;  // ... with this marker array
-    uint32_t stamp = 0;
+    SeenScratch seen_scratch;  // ... with this marker array
     bool use_graph = false;  // f2v_train replays one hipGraph per epoch parity instead of launching eagerly
     f2v_stats stats{};
     // multi-GPU push exchange (include/f2v.h): peers' matrices and flags mapped through HIP IPC
@@ -314,11 +323,11 @@ bool is_split(const f2v_ctx *c, uint32_t i) { return c->chunk != 0 && c->rowptr[
 // row it writes once, its neighbour ids and work items once -- what would still cross HBM if everything read twice inside
 // the minibatch came from a cache the second time.  (The ns sampled rows, the partial sums of split rows and rowptr are
 // left out: a lower bound.)
-uint64_t compulsory_bytes(f2v_ctx *c, uint32_t row_lo, uint32_t row_hi, bool walk, uint64_t nnz, uint64_t n_items) {
-    if (c->seen_stamp.size() != c->n) { c->seen_stamp.assign(c->n, 0u); c->stamp = 0; }
-    if (++c->stamp == 0) { std::fill(c->seen_stamp.begin(), c->seen_stamp.end(), 0u); c->stamp = 1; }
-    const uint32_t st = c->stamp;
-    uint32_t *seen = c->seen_stamp.data();
+uint64_t compulsory_bytes(const f2v_ctx *c, SeenScratch &sc, uint32_t row_lo, uint32_t row_hi, bool walk, uint64_t nnz, uint64_t n_items) {
+    if (sc.seen.size() != c->n) { sc.seen.assign(c->n, 0u); sc.stamp = 0; }
+    if (++sc.stamp == 0) { std::fill(sc.seen.begin(), sc.seen.end(), 0u); sc.stamp = 1; }
+    const uint32_t st = sc.stamp;
+    uint32_t *seen = sc.seen.data();
     uint64_t distinct = 0;
     const uint32_t *ids = walk ? nullptr : c->colids.data();
     for (uint32_t i = row_lo; i < row_hi; i++) {
@@ -508,7 +517,7 @@ const Plan &plan_for(f2v_ctx *c, uint32_t row_lo, uint32_t row_hi, bool walk) {
     }
     p.n_slots = slots;
     if (slots > kItemSlotMask) c->plan_overflow = true;  // the slot index would run into the item's flag bits: the caller fails the call
-    if (c->count_compulsory) p.compulsory = compulsory_bytes(c, row_lo, row_hi, walk, p.nnz, p.n_items);
+    if (c->count_compulsory) p.compulsory = compulsory_bytes(c, c->seen_scratch, row_lo, row_hi, walk, p.nnz, p.n_items);
     c->max_slots = std::max<size_t>(c->max_slots, slots);
     return c->plans.emplace(key, p).first->second;
 }
@@ -543,9 +552,9 @@ bool chain_usable(const f2v_ctx *c, int math, uint32_t batch, int bs_mode, bool 
     (void)math;     // option 7 chains too: its five walk samples per row are gathered (and waited for) like CSR neighbours
     // rows narrower than a 128-byte line (D = 16, 8, 4 ...): only in the wide form, whose handed-off rows are read with agent-scope
     // loads alone, and only where no line holds rows of two minibatches (every reader then treats all of a line's rows alike)
-    const bool lines_ok = c->D % 32u == 0u || (wide_usable(c) && batch <= c->wide_max_batch && chain_len(c, batch, true) >= 2 && ((uint64_t)batch * c->D) % 32u == 0u);
+    const bool lines_ok = c->D % 32u == 0u || (wide_usable(c) && batch <= c->wide_max_batch && (chain_len(c, batch, true) >= 2 || c->wide_single) && ((uint64_t)batch * c->D) % 32u == 0u);
     return c->chain && !sharded && c->merge_fin && c->xcc_round_robin && !c->capturing && !c->use_graph &&
-           subwave_width(c) != 0 && lines_ok && batch <= c->chain_max_batch && nb >= 2 && chain_len(c, batch) >= 2;
+           subwave_width(c) != 0 && lines_ok && batch <= c->chain_max_batch && nb >= 2 && (chain_len(c, batch) >= 2 || c->wide_single);
 }
 
 // The work of minibatches [b0, b0+K) of batch size `batch` as ONE launch: per minibatch its items (rows whose neighbours all
@@ -631,7 +640,13 @@ const ChainPlan &chain_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t ba
         bd.index = b0 + k;
         const size_t wg_at = c->h_wg.size();  // (fin_n is known only below: the descriptors are patched then)
         for (uint32_t w = 0; w < bd.step_blocks; w++) { bd.blk = w; c->h_wg.push_back(bd); }
-        for (const DI &d : items) c->h_items.push_back(d.it);
+        for (const DI &d : items) {
+            Item it = d.it;
+            // (the CSR tells: no neighbour lies in the launch's earlier minibatches -- the kernel walks such an item's list like the
+            // plain launch form; walk samples change every epoch and say nothing)
+            if (!walk && d.dep == 0) it.flags |= kItemIndep;
+            c->h_items.push_back(it);
+        }
         // the combine trees of this minibatch's split rows, level by level (fan-in groups in chunk order, as plan_for)
         uint32_t fin_n = 0;
         for (int level = 0; !cur.empty(); level++) {
@@ -664,7 +679,7 @@ const ChainPlan &chain_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t ba
         p.n_wgs += bd.step_blocks + node_blocks;
         p.n_fin += fin_n;
         p.nnz += nnz;
-        if (c->count_compulsory) p.compulsory += compulsory_bytes(c, lo, hi, walk, nnz, bd.n_items);
+        if (c->count_compulsory) p.compulsory += compulsory_bytes(c, c->seen_scratch, lo, hi, walk, nnz, bd.n_items);
     }
     p.n_slots = slots;
     if (slots > kItemSlotMask) c->plan_overflow = true;
@@ -677,11 +692,15 @@ const ChainPlan &chain_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t ba
 // then their finishers, then the workgroups that pack whole low-degree rows and rows of one fan-in group, then the
 // combine-tree nodes above the units of rows with more than fanin^2 pieces.  Pieces (piece_cuts), fan-in groups and the
 // order of every addition are those of plan_for / chain_plan_for: the result does not depend on which form ran.
-const WidePlan &wide_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t batch, bool walk) {
-    const auto key = std::make_tuple(b0, K, batch, walk ? 1 : 0);
-    auto itp = c->wides.find(key);
-    if (itp != c->wides.end()) return itp->second;
-    if (c->h_items.size() > plan_cache_limit(c)) drop_plans(c);
+// (built into vectors of its own, offsets relative to them: the plans of an epoch are independent of each other and are built by
+// several host threads, wide_plans_for_epoch -- one thread took 0.33 s for RMAT-20 at batch 256 and, by the same count, ~5 s for RMAT-24)
+struct WideParts {
+    std::vector<Item> items;
+    std::vector<WJob> jobs;
+    std::vector<WideDesc> wide;
+    std::vector<FinItem> hubs;
+};
+WidePlan build_wide_plan(const f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t batch, bool walk, WideParts &out, SeenScratch &seen) {
     const uint32_t layout = wide_width(c, batch);
     const uint32_t ipb = wide_items_per_block(layout);        // lane groups per workgroup = items per round
     const uint32_t pslots = std::max<uint32_t>(ipb, 32u);      // piece slots of a phase (PSLOTS of the kernel)
@@ -690,10 +709,7 @@ const WidePlan &wide_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t batc
     p.width = layout;
     p.first_batch = b0;
     p.n_batches = K;
-    p.item_off = c->h_items.size();
-    p.fin_off = c->h_hubs.size();
-    p.wg_off = c->h_wide.size();
-    p.job_off = c->h_jobs.size();
+    p.item_off = p.fin_off = p.wg_off = p.job_off = 0;  // (relative to `out`; wide_plan_append moves them)
     p.lo = (uint32_t)std::min<uint64_t>((uint64_t)b0 * batch, c->n);
     uint32_t slots = 0;  // partial sums in HBM: helpers' group sums, units' sums, upper tree levels
 
@@ -919,13 +935,13 @@ const WidePlan &wide_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t batc
                 d.lo = lo;
                 d.index = b0 + k;
                 d.kind = 0;
-                d.a = (uint32_t)(c->h_items.size() - p.item_off);
+                d.a = (uint32_t)out.items.size();
                 d.b = (uint32_t)(g.items.size() / ipb);
-                d.c = (uint32_t)(c->h_jobs.size() - p.job_off);
+                d.c = (uint32_t)out.jobs.size();
                 d.d = (uint32_t)g.jobs.size();
-                c->h_items.insert(c->h_items.end(), g.items.begin(), g.items.end());
-                c->h_jobs.insert(c->h_jobs.end(), g.jobs.begin(), g.jobs.end());
-                c->h_wide.push_back(d);
+                out.items.insert(out.items.end(), g.items.begin(), g.items.end());
+                out.jobs.insert(out.jobs.end(), g.jobs.begin(), g.jobs.end());
+                out.wide.push_back(d);
                 mb_items += (uint32_t)g.items.size();
                 p.n_wgs++;
             }
@@ -940,7 +956,7 @@ const WidePlan &wide_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t batc
         emit(finishers);
         if (c->wide_order == 0) emit(packed);
         // the combine trees above the units of rows with more than F*F pieces, level by level
-        const uint32_t fin_first = (uint32_t)(c->h_hubs.size() - p.fin_off);
+        const uint32_t fin_first = (uint32_t)out.hubs.size();
         uint32_t fin_n = 0;
         for (int level = 0; !cur.empty(); level++) {
             nxt.clear();
@@ -948,11 +964,11 @@ const WidePlan &wide_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t batc
                 const uint32_t G = (level == kMaxFinLevels - 1) ? nd.n : F;
                 const uint32_t nout = (nd.n + G - 1) / G;
                 if (nout == 1) {
-                    c->h_hubs.push_back(FinItem{nd.in_slot, nd.n, kFinToStage, nd.row});
+                    out.hubs.push_back(FinItem{nd.in_slot, nd.n, kFinToStage, nd.row});
                     fin_n++;
                 } else {
                     for (uint32_t o = 0; o < nout; o++) {
-                        c->h_hubs.push_back(FinItem{nd.in_slot + o * G, std::min(G, nd.n - o * G), slots + o, nd.row});
+                        out.hubs.push_back(FinItem{nd.in_slot + o * G, std::min(G, nd.n - o * G), slots + o, nd.row});
                         fin_n++;
                     }
                     nxt.push_back(Node{nd.row, slots, nout});
@@ -961,7 +977,7 @@ const WidePlan &wide_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t batc
             }
             cur.swap(nxt);
         }
-        while (fin_n % 4u != 0) { c->h_hubs.push_back(FinItem{0, 0, kFinToStage, 0}); fin_n++; }
+        while (fin_n % 4u != 0) { out.hubs.push_back(FinItem{0, 0, kFinToStage, 0}); fin_n++; }
         for (uint32_t wn = 0; wn < fin_n / 4u; wn++) {
             WideDesc d{};
             d.lo = lo;
@@ -970,18 +986,79 @@ const WidePlan &wide_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t batc
             d.a = fin_first;
             d.b = fin_n;
             d.c = wn;
-            c->h_wide.push_back(d);
+            out.wide.push_back(d);
             p.n_wgs++;
             p.n_node_wgs++;
         }
         p.nnz += nnz;
-        if (c->count_compulsory) p.compulsory += compulsory_bytes(c, lo, hi, walk, nnz, mb_items);
+        if (c->count_compulsory) p.compulsory += compulsory_bytes(c, seen, lo, hi, walk, nnz, mb_items);
     }
     p.n_slots = slots;
+    return p;
+}
+
+// a built plan joins the handle's resident arrays
+const WidePlan &wide_plan_append(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t batch, bool walk, WidePlan p, const WideParts &parts) {
+    p.item_off = c->h_items.size();
+    p.fin_off = c->h_hubs.size();
+    p.wg_off = c->h_wide.size();
+    p.job_off = c->h_jobs.size();
+    c->h_items.insert(c->h_items.end(), parts.items.begin(), parts.items.end());
+    c->h_jobs.insert(c->h_jobs.end(), parts.jobs.begin(), parts.jobs.end());
+    c->h_wide.insert(c->h_wide.end(), parts.wide.begin(), parts.wide.end());
+    c->h_hubs.insert(c->h_hubs.end(), parts.hubs.begin(), parts.hubs.end());
     // (the helpers' group sums are imported at 32-bit byte offsets: load16_agent)
-    if (slots > kItemSlotMask || (uint64_t)slots * c->D * sizeof(float) > 0xFFFFFFFFull) c->plan_overflow = true;
-    c->max_slots = std::max<size_t>(c->max_slots, slots);
-    return c->wides.emplace(key, p).first->second;
+    if (p.n_slots > kItemSlotMask || (uint64_t)p.n_slots * c->D * sizeof(float) > 0xFFFFFFFFull) c->plan_overflow = true;
+    c->max_slots = std::max<size_t>(c->max_slots, p.n_slots);
+    return c->wides.emplace(std::make_tuple(b0, K, batch, walk ? 1 : 0), p).first->second;
+}
+
+const WidePlan &wide_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t batch, bool walk) {
+    auto itp = c->wides.find(std::make_tuple(b0, K, batch, walk ? 1 : 0));
+    if (itp != c->wides.end()) return itp->second;
+    if (c->h_items.size() > plan_cache_limit(c)) drop_plans(c);
+    WideParts parts;
+    const WidePlan p = build_wide_plan(c, b0, K, batch, walk, parts, c->seen_scratch);
+    return wide_plan_append(c, b0, K, batch, walk, p, parts);
+}
+
+// Every wide-form plan of an epoch (launch l covers minibatches [l*K, l*K + K)): the missing ones are built side by side on the
+// host's threads -- a plan reads the graph and the handle's parameters only -- and appended in launch order, so that the resident
+// arrays are the ones a serial build leaves (F2V_IO_THREADS bounds the threads; a thread that counts compulsory bytes holds 4 N bytes
+// of stamps).
+void wide_plans_for_epoch(f2v_ctx *c, uint32_t nb, uint32_t K, uint32_t batch, bool walk) {
+    std::vector<uint32_t> todo;
+    for (uint32_t b0 = 0; b0 < nb; b0 += K)
+        if (!c->wides.count(std::make_tuple(b0, std::min(K, nb - b0), batch, walk ? 1 : 0))) todo.push_back(b0);
+    if (todo.empty()) return;
+    if (c->h_items.size() > plan_cache_limit(c)) {
+        drop_plans(c);
+        todo.clear();
+        for (uint32_t b0 = 0; b0 < nb; b0 += K) todo.push_back(b0);
+    }
+    unsigned T = std::thread::hardware_concurrency();
+    if (const char *e = getenv("F2V_IO_THREADS")) T = (unsigned)atoi(e);
+    T = std::max(1u, std::min<unsigned>({T, 32u, (unsigned)todo.size()}));
+    if (c->count_compulsory) T = std::min<unsigned>(T, std::max<unsigned>(1u, (unsigned)((1ull << 30) / std::max<uint64_t>(4ull * c->n, 1))));  // <= 1 GiB of stamps
+    if (T == 1 || (uint64_t)c->nnz < (1ull << 22)) {  // small graphs: a thread costs more than the plan
+        for (uint32_t b0 : todo) (void)wide_plan_for(c, b0, std::min(K, nb - b0), batch, walk);
+        return;
+    }
+    std::vector<WideParts> parts(todo.size());
+    std::vector<WidePlan> plans(todo.size());
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; t++)
+        th.emplace_back([&] {
+            SeenScratch seen;
+            for (size_t k; (k = next.fetch_add(1)) < todo.size();)
+                plans[k] = build_wide_plan(c, todo[k], std::min(K, nb - todo[k]), batch, walk, parts[k], seen);
+        });
+    for (auto &y : th) y.join();
+    for (size_t k = 0; k < todo.size(); k++) {
+        (void)wide_plan_append(c, todo[k], std::min(K, nb - todo[k]), batch, walk, plans[k], parts[k]);
+        parts[k] = WideParts{};  // (release as we go: the parts are a second copy of the epoch's plans)
+    }
 }
 
 // Make every plan built so far resident in HBM (and the partial-sum buffer large enough).
@@ -989,7 +1066,7 @@ int upload_plans(f2v_ctx *c) {
     if (c->plan_overflow) {
         c->plan_overflow = false;
         drop_plans(c);
-        return fail(F2V_EINVAL, "a launch plan needs more than 2^28 partial-sum slots (or, in the wide form, 4 GiB of them): use a larger \"hub_chunk\" or fewer \"chain_rows\" / \"wide_rows\"");
+        return fail(F2V_EINVAL, "a launch plan needs more than 2^27 partial-sum slots (or, in the wide form, 4 GiB of them): use a larger \"hub_chunk\" or fewer \"chain_rows\" / \"wide_rows\"");
     }
     const size_t need_slots = c->max_slots;
     const bool grow_items = c->h_items.size() > c->d_items_cap, grow_hubs = c->h_hubs.size() > c->d_hubs_cap;
@@ -1943,7 +2020,7 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
         if (rc != F2V_OK) return rc;
         HIPC(hipStreamSynchronize(c->stream));
         if (value > (int64_t)kItemSlotMask) return fail(F2V_EINVAL, "hub_chunk out of range");
-        // partial-sum slots are 28-bit: pieces plus the nodes of their combine trees must stay below 2^28
+        // partial-sum slots are 27-bit: pieces plus the nodes of their combine trees must stay below 2^27
         if (value > 0 && c->nnz / (uint64_t)value >= (1ull << 27)) return fail(F2V_EINVAL, "hub_chunk %lld is too small for %llu nonzeros", (long long)value, (unsigned long long)c->nnz);
         c->chunk = (uint32_t)value;
         c->chunk_auto = false;
@@ -2047,6 +2124,10 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
     if (!strcmp(name, "wide_epochs")) {
         if (value < 0 || value > 1024) return fail(F2V_EINVAL, "wide_epochs must be 0 (automatic) ... 1024");
         c->wide_epochs = (uint32_t)value;
+        return F2V_OK;
+    }
+    if (!strcmp(name, "wide_single")) {
+        c->wide_single = value != 0;
         return F2V_OK;
     }
     if (!strcmp(name, "wide_samples_early")) {
@@ -2179,6 +2260,7 @@ int f2v_get_param(f2v_handle c, const char *name, int64_t *out) {
     if (!strcmp(name, "wide_phases")) { *out = c->wide_phases; return F2V_OK; }
     if (!strcmp(name, "wide_max_batch")) { *out = c->wide_max_batch; return F2V_OK; }
     if (!strcmp(name, "wide_min_width")) { *out = c->wide_min_width; return F2V_OK; }
+    if (!strcmp(name, "wide_single")) { *out = c->wide_single ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "wide_samples_early")) { *out = c->wide_samples_early; return F2V_OK; }
     if (!strcmp(name, "wide_epochs")) { *out = c->wide_epochs; return F2V_OK; }
     if (!strcmp(name, "last_wide_epochs")) { *out = c->last_wide_epochs; return F2V_OK; }
@@ -2520,7 +2602,7 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
     const bool all_upfront = (math != 7 || c->fast_rng) && (per_epoch * iters * 4ull <= (1ull << 30));
     // small minibatches: groups of them in one launch (chain_plan_for), ordered by data dependencies instead of launch boundaries
     const bool chained = iters > 0 && chain_usable(c, math, batch, bs_mode, sharded);
-    const bool wide = chained && wide_usable(c) && batch <= c->wide_max_batch && chain_len(c, batch, true) >= 2;
+    const bool wide = chained && wide_usable(c) && batch <= c->wide_max_batch && (chain_len(c, batch, true) >= 2 || c->wide_single);
     const uint32_t K = chained ? chain_len(c, batch, wide) : 1;
     uint32_t epochs_max = 1;  // "wide_epochs"
     if (wide && all_upfront && math != 7 && !bs_mode && ns <= 8 && !c->mark_every
@@ -2535,7 +2617,7 @@ int train_impl(f2v_ctx *c, int option, uint32_t iters, uint32_t batch, uint32_t 
     c->last_wide_epochs = 1;
     c->last_train_form = 0;  // (set where a launch is made: launch_step 0 / 3 under hipGraph replay, launch_chain 1, launch_wide 2)
     if (wide) {
-        for (uint32_t b0 = 0; b0 < nb; b0 += K) (void)wide_plan_for(c, b0, std::min(K, nb - b0), batch, math == 7);
+        wide_plans_for_epoch(c, nb, K, batch, math == 7);
     } else if (chained) {
         for (uint32_t b0 = 0; b0 < nb; b0 += K) (void)chain_plan_for(c, b0, std::min(K, nb - b0), batch, math == 7);
     } else {

@@ -1226,8 +1226,15 @@ def test_bench_contract_on_a_small_graph(tmp_path):
     assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and 0.0 < roof["frac"] <= 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
     assert roof["compulsory_bytes_per_launch"] <= roof["algorithmic_bytes_per_launch"] and "qstep" in roof["kernel"]
     assert res["config"]["verified_rows"] >= 24 and "failed" not in res
-    assert set(res["extra"]) == {"batch_384", "batch_2048", "config5_rmat16_option11", "sustained", "config0_cora_D16", "config1_cora_D128"}
+    assert set(res["extra"]) == {"batch_384", "batch_2048", "config5_rmat16_option11", "sustained", "config0_cora_D16", "config1_cora_D128", "option7"}
     assert res["extra"]["config5_rmat16_option11"]["verified_rows"] >= 24
+    # the counters of the roofline object are measured by the run itself (rocprofv3 --pmc passes over a child run), or the line says why not
+    assert (roof["traffic"] is not None and "measured by this run" in roof["traffic_source"] and roof["traffic"] >= roof["compulsory_bytes_per_launch"] * 0.9
+            and 0.0 < roof["l2_hit_rate"] < 1.0) or "traffic_note" in roof, roof
+    assert ("(> 1)" in roof["algorithmic_frac_note"]) == (roof["algorithmic_GBs"] > 8000.0)
+    assert res["config"]["recoveries"] == 0 and res["config"]["merge_finalize"] == 1 and res["config"]["snapshot_copy_ms_per_train_call"] >= 0.0
+    o7 = res["extra"]["option7"]
+    assert o7["ms_per_epoch"] > 0 and o7["host_walk_generation_ms_per_epoch"] > 0 and 0 < o7["device_only_ms_per_epoch_fast_rng"] <= o7["ms_per_epoch"] * 1.5
     sus = res["extra"]["sustained"]
     assert sus["seconds_device"] >= 0.15 and sus["epochs"] >= 8 and sus["edges_per_s"] > 0
     for key in ("config0_cora_D16", "config1_cora_D128"):  # BASELINE configs[0] / [1], with their in-run checks against the reference's output
