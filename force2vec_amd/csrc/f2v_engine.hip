@@ -129,7 +129,7 @@ struct f2v_ctx {
     uint32_t last_wide_width = 0;  // the layout width of the last wide-form f2v_train ("last_wide_width")
     bool last_wide_early = false;  // ... and whether it ran the kernel's EARLY form ("last_wide_early")
     int last_train_form = 0;  // how the last f2v_train launched: 0 one launch per minibatch, 1 chained, 2 chained in the wide form ("last_train_form")
-    bool plan_overflow = false;  // a launch plan needed more than 2^27 partial-sum slots (kItemSlotMask)
+    bool plan_overflow = false;  // a launch plan needed more than 2^28 partial-sum slots (kItemSlotMask)
     uint32_t *h_kerr = nullptr;  // pinned: the kernel error words as of the last completed epoch-end copy (train_impl)
 #ifdef F2V_TEST_HOOKS
     uint32_t test_withhold_slot = kNoSlot, test_withhold_row = kNoSlot;
@@ -640,13 +640,7 @@ const ChainPlan &chain_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t ba
         bd.index = b0 + k;
         const size_t wg_at = c->h_wg.size();  // (fin_n is known only below: the descriptors are patched then)
         for (uint32_t w = 0; w < bd.step_blocks; w++) { bd.blk = w; c->h_wg.push_back(bd); }
-        for (const DI &d : items) {
-            Item it = d.it;
-            // (the CSR tells: no neighbour lies in the launch's earlier minibatches -- the kernel walks such an item's list like the
-            // plain launch form; walk samples change every epoch and say nothing)
-            if (!walk && d.dep == 0) it.flags |= kItemIndep;
-            c->h_items.push_back(it);
-        }
+        for (const DI &d : items) c->h_items.push_back(d.it);
         // the combine trees of this minibatch's split rows, level by level (fan-in groups in chunk order, as plan_for)
         uint32_t fin_n = 0;
         for (int level = 0; !cur.empty(); level++) {
@@ -1026,7 +1020,7 @@ const WidePlan &wide_plan_for(f2v_ctx *c, uint32_t b0, uint32_t K, uint32_t batc
 // host's threads -- a plan reads the graph and the handle's parameters only -- and appended in launch order, so that the resident
 // arrays are the ones a serial build leaves (F2V_IO_THREADS bounds the threads; a thread that counts compulsory bytes holds 4 N bytes
 // of stamps).
-void wide_plans_for_epoch(f2v_ctx *c, uint32_t nb, uint32_t K, uint32_t batch, bool walk) {
+void wide_plans_for_epoch(f2v_ctx *c, uint32_t nb, uint32_t K, uint32_t batch, bool walk, unsigned force_threads = 0) {
     std::vector<uint32_t> todo;
     for (uint32_t b0 = 0; b0 < nb; b0 += K)
         if (!c->wides.count(std::make_tuple(b0, std::min(K, nb - b0), batch, walk ? 1 : 0))) todo.push_back(b0);
@@ -1040,7 +1034,8 @@ void wide_plans_for_epoch(f2v_ctx *c, uint32_t nb, uint32_t K, uint32_t batch, b
     if (const char *e = getenv("F2V_IO_THREADS")) T = (unsigned)atoi(e);
     T = std::max(1u, std::min<unsigned>({T, 32u, (unsigned)todo.size()}));
     if (c->count_compulsory) T = std::min<unsigned>(T, std::max<unsigned>(1u, (unsigned)((1ull << 30) / std::max<uint64_t>(4ull * c->n, 1))));  // <= 1 GiB of stamps
-    if (T == 1 || (uint64_t)c->nnz < (1ull << 22)) {  // small graphs: a thread costs more than the plan
+    if (force_threads) T = std::max(2u, std::min<unsigned>(force_threads, (unsigned)todo.size()));  // (the self-test hook: the threaded path on any graph)
+    if (T == 1 || (!force_threads && (uint64_t)c->nnz < (1ull << 22))) {  // small graphs: a thread costs more than the plan
         for (uint32_t b0 : todo) (void)wide_plan_for(c, b0, std::min(K, nb - b0), batch, walk);
         return;
     }
@@ -1066,7 +1061,7 @@ int upload_plans(f2v_ctx *c) {
     if (c->plan_overflow) {
         c->plan_overflow = false;
         drop_plans(c);
-        return fail(F2V_EINVAL, "a launch plan needs more than 2^27 partial-sum slots (or, in the wide form, 4 GiB of them): use a larger \"hub_chunk\" or fewer \"chain_rows\" / \"wide_rows\"");
+        return fail(F2V_EINVAL, "a launch plan needs more than 2^28 partial-sum slots (or, in the wide form, 4 GiB of them): use a larger \"hub_chunk\" or fewer \"chain_rows\" / \"wide_rows\"");
     }
     const size_t need_slots = c->max_slots;
     const bool grow_items = c->h_items.size() > c->d_items_cap, grow_hubs = c->h_hubs.size() > c->d_hubs_cap;
@@ -2020,7 +2015,7 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
         if (rc != F2V_OK) return rc;
         HIPC(hipStreamSynchronize(c->stream));
         if (value > (int64_t)kItemSlotMask) return fail(F2V_EINVAL, "hub_chunk out of range");
-        // partial-sum slots are 27-bit: pieces plus the nodes of their combine trees must stay below 2^27
+        // partial-sum slots are 28-bit: pieces plus the nodes of their combine trees must stay below 2^28
         if (value > 0 && c->nnz / (uint64_t)value >= (1ull << 27)) return fail(F2V_EINVAL, "hub_chunk %lld is too small for %llu nonzeros", (long long)value, (unsigned long long)c->nnz);
         c->chunk = (uint32_t)value;
         c->chunk_auto = false;
@@ -2261,6 +2256,10 @@ int f2v_get_param(f2v_handle c, const char *name, int64_t *out) {
     if (!strcmp(name, "wide_max_batch")) { *out = c->wide_max_batch; return F2V_OK; }
     if (!strcmp(name, "wide_min_width")) { *out = c->wide_min_width; return F2V_OK; }
     if (!strcmp(name, "wide_single")) { *out = c->wide_single ? 1 : 0; return F2V_OK; }
+    if (!strcmp(name, "plan_resident_bytes")) {  // launch plans resident on the host (and, uploaded, in HBM): items, jobs, workgroup descriptors, tree nodes
+        *out = (int64_t)(c->h_items.size() * sizeof(Item) + c->h_jobs.size() * sizeof(WJob) + c->h_wide.size() * sizeof(WideDesc) + c->h_wg.size() * sizeof(WgDesc) + c->h_hubs.size() * sizeof(FinItem));
+        return F2V_OK;
+    }
     if (!strcmp(name, "wide_samples_early")) { *out = c->wide_samples_early; return F2V_OK; }
     if (!strcmp(name, "wide_epochs")) { *out = c->wide_epochs; return F2V_OK; }
     if (!strcmp(name, "last_wide_epochs")) { *out = c->last_wide_epochs; return F2V_OK; }
@@ -3104,12 +3103,13 @@ int f2v_test_chain_nowait(f2v_handle c, int on) {
 //     stay inside the LDS slot space, passes hold at most 8 jobs, a job adds consecutive pieces of ONE row in neighbour order;
 //   * WAITS ONLY POINT BACKWARDS: a helper's group sum is produced by a workgroup with a smaller index than the finisher that
 //     imports it, every sum a combine-tree node adds by a smaller index than the node's, minibatches appear in order.
-// stats_out[0..5]: workgroups, helpers, finishers, packed workgroups, node workgroups, partial-sum slots.
+// stats_out[0..6]: workgroups, helpers, finishers, packed workgroups, node workgroups, partial-sum slots, a checksum of the plan arrays.
 int f2v_test_wide_plan_check(const uint32_t *rowptr, const uint32_t *colids, uint32_t n, uint64_t nnz, uint32_t dim, uint32_t batch, int walk,
                              const char *const *names, const int64_t *values, uint32_t n_params, uint64_t *stats_out) {
     if (!rowptr || (!colids && nnz) || n < 2 || dim == 0 || batch == 0) return fail(F2V_EINVAL, "f2v_test_wide_plan_check: bad argument");
     f2v_ctx ctx;
     f2v_ctx *c = &ctx;
+    unsigned plan_threads = 0;
     c->n = n; c->nnz = nnz; c->D = dim;
     c->rowptr.assign(rowptr, rowptr + n + 1);
     c->colids.assign(colids, colids + nnz);
@@ -3127,13 +3127,15 @@ int f2v_test_wide_plan_check(const uint32_t *rowptr, const uint32_t *colids, uin
         else if (nm == "wide_order") c->wide_order = (uint32_t)v;
         else if (nm == "wide_rows") c->wide_rows = (uint32_t)v;
         else if (nm == "wide_min_width") c->wide_min_width = (uint32_t)v;
+        else if (nm == "plan_threads") plan_threads = (unsigned)v;  // build the epoch's plans on this many host threads (wide_plans_for_epoch)
         else return fail(F2V_EINVAL, "f2v_test_wide_plan_check: unknown parameter '%s'", nm.c_str());
     }
     if (!wide_usable(c) || subwave_width(c) == 0) return fail(F2V_EINVAL, "f2v_test_wide_plan_check: the wide form does not run this shape");
     const uint32_t nb = (uint32_t)(((uint64_t)n + batch - 1) / batch), K = chain_len(c, batch, true);
     const uint32_t width = wide_width(c, batch), ipb = wide_items_per_block(width), pslots = std::max<uint32_t>(ipb, 32u), F = c->fanin;
     std::vector<uint32_t> finished(n, 0), covered(nnz, 0);
-    uint64_t st[6] = {};
+    uint64_t st[7] = {};
+    if (plan_threads) wide_plans_for_epoch(c, nb, K, batch, walk != 0, plan_threads);
 #define F2V_PLAN_FAIL(...) return fail(F2V_ESTATE, "f2v_test_wide_plan_check: " __VA_ARGS__)
     for (uint32_t b0 = 0; b0 < nb; b0 += K) {
         const WidePlan p = wide_plan_for(c, b0, std::min(K, nb - b0), batch, walk != 0);
@@ -3263,6 +3265,18 @@ int f2v_test_wide_plan_check(const uint32_t *rowptr, const uint32_t *colids, uin
     if (!walk)
         for (uint64_t e = 0; e < nnz; e++)
             if (covered[e] != 1) return fail(F2V_ESTATE, "f2v_test_wide_plan_check: neighbour %llu is in %u pieces", (unsigned long long)e, covered[e]);
+    {   // [6]: a checksum of the resident plan arrays (items, jobs, descriptors, tree nodes): the threaded build leaves the serial build's
+        uint64_t h = 1469598103934665603ull;
+        auto mix = [&](const void *p, size_t bytes) {
+            const unsigned char *q = static_cast<const unsigned char *>(p);
+            for (size_t k = 0; k < bytes; k++) h = (h ^ q[k]) * 1099511628211ull;
+        };
+        mix(c->h_items.data(), c->h_items.size() * sizeof(Item));
+        mix(c->h_jobs.data(), c->h_jobs.size() * sizeof(WJob));
+        mix(c->h_wide.data(), c->h_wide.size() * sizeof(WideDesc));
+        mix(c->h_hubs.data(), c->h_hubs.size() * sizeof(FinItem));
+        st[6] = h;
+    }
     if (stats_out) memcpy(stats_out, st, sizeof st);
     return F2V_OK;
 }

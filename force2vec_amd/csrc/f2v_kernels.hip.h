@@ -57,13 +57,12 @@ struct Item {
     uint32_t row;    // source vertex
     uint32_t nb;     // first index into nbr_ids
     uint32_t cnt;    // neighbours in this item
-    uint32_t flags;  // kItem* bits | partial slot (low 27 bits)
+    uint32_t flags;  // kItem* bits | partial slot (low 28 bits)
 };
 constexpr uint32_t kItemPartial = 1u << 31;  // store the force sum to partials[slot] (hub chunk), not the new row
 constexpr uint32_t kItemFirst = 1u << 30;    // first chunk of its row (sigmoid: accumulates onto x_i)
 constexpr uint32_t kItemLast = 1u << 29;     // last chunk of its row: also takes the negative samples
-constexpr uint32_t kItemIndep = 1u << 27;   // chained launches (round-2 form): no neighbour of the item is a row an earlier minibatch of the launch writes
-constexpr uint32_t kItemSlotMask = (1u << 27) - 1;
+constexpr uint32_t kItemSlotMask = (1u << 28) - 1;
 
 // One node of a hub row's combine tree: add partial rows [in_slot, in_slot+n) in order.
 struct FinItem {
@@ -1103,14 +1102,7 @@ __device__ __forceinline__ void qstep_body(const StepArgs &a, const uint32_t blk
     }
 
     bool bad = false;  // chained minibatches: a wait for an earlier minibatch's row gave up -- this item stores nothing
-    // A chained launch sorts a minibatch's items independent-first, and the host has marked them (kItemIndep: no neighbour is a row
-    // the launch hands on): a wavefront of such items walks its lists exactly as the plain launch form does -- no window test, no
-    // choice of load per row (round 3 made that choice per row and lane in every wavefront: +2-3 % at batch 4096, where 94 % of the
-    // gathers are plain).
-    bool walk_plain = !CHAIN;
-    if constexpr (CHAIN) walk_plain = __builtin_amdgcn_ballot_w64(active && !(it.flags & kItemIndep)) == 0ull;  // (wave-uniform)
-    if (walk_plain) qprocess<OPT, LPI, NB, false, U, FULL, false>(a, hs, a.nbr_ids + it.nb, it.cnt, wave_max_of_items<LPI>(it.cnt), t, D, xi, Y, c0, table, bad);
-    else qprocess<OPT, LPI, NB, false, U, FULL, CHAIN>(a, hs, a.nbr_ids + it.nb, it.cnt, wave_max_of_items<LPI>(it.cnt), t, D, xi, Y, c0, table, bad);
+    qprocess<OPT, LPI, NB, false, U, FULL, CHAIN>(a, hs, a.nbr_ids + it.nb, it.cnt, wave_max_of_items<LPI>(it.cnt), t, D, xi, Y, c0, table, bad);
     if (lds_samples) {
         if (active && last_chunk) {
             for (uint32_t sidx = 0; sidx < a.ns; ++sidx) {

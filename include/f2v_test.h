@@ -41,10 +41,12 @@ F2V_API int f2v_test_chain_nowait(f2v_handle h, int on);
 F2V_API int f2v_test_stamps(f2v_handle h, int on, unsigned long long *out);
 
 /* Host-only (no device): builds the wide form's launch plans of one epoch for this graph, batch and tunables (`names` / `values`:
- * hub_chunk, hub_fanin, class_cut, wide_phases, wide_rounds, wide_span, wide_finish, wide_order, wide_rows, wide_min_width) and
+ * hub_chunk, hub_fanin, class_cut, wide_phases, wide_rounds, wide_span, wide_finish, wide_order, wide_rows, wide_min_width; plan_threads = T
+ * builds them on T host threads as f2v_train does for large graphs) and
  * checks what the kernel relies on: every row finished once, every neighbour in one piece, rounds / phases / slots / passes
  * well-formed, a job adds consecutive pieces of one row, and every wait (an imported group sum, a tree node's inputs) points at a
- * workgroup with a SMALLER index.  stats_out[6]: workgroups, helpers, finishers, packed, node workgroups, partial-sum slots. */
+ * workgroup with a SMALLER index.  stats_out[7]: workgroups, helpers, finishers, packed, node workgroups, partial-sum slots, a checksum of
+ * the resident plan arrays. */
 F2V_API int f2v_test_wide_plan_check(const uint32_t *rowptr, const uint32_t *colids, uint32_t n, uint64_t nnz, uint32_t dim, uint32_t batch, int walk,
                              const char *const *names, const int64_t *values, uint32_t n_params, uint64_t *stats_out);
 

@@ -21,12 +21,12 @@ def check(rowptr, colids, dim, batch, walk=0, **params):
     colids = np.ascontiguousarray(colids, dtype=np.uint32)
     names = (C.c_char_p * len(params))(*[k.encode() for k in params])
     values = (C.c_int64 * len(params))(*[int(v) for v in params.values()])
-    stats = (C.c_uint64 * 6)()
+    stats = (C.c_uint64 * 7)()
     rc = T.f2v_test_wide_plan_check(rowptr.ctypes.data_as(_lib.u32p), colids.ctypes.data_as(_lib.u32p), len(rowptr) - 1, len(colids), dim, batch, walk,
                                     names, values, len(params), stats)
     if rc != 0:
         raise AssertionError(T.f2v_last_error().decode())
-    return dict(zip(("workgroups", "helpers", "finishers", "packed", "node_workgroups", "slots"), [int(x) for x in stats]))
+    return dict(zip(("workgroups", "helpers", "finishers", "packed", "node_workgroups", "slots", "checksum"), [int(x) for x in stats]))
 
 
 @pytest.fixture(scope="module")
@@ -63,6 +63,19 @@ def test_wide_plans_on_the_reference_graphs(graph, dim, batch):
     check(rowptr, colids, dim, batch)
     check(rowptr, colids, dim, batch, walk=1)      # option 7: every row is one item of five walk samples
     check(rowptr, colids, dim, batch, hub_fanin=4, wide_finish=2, wide_span=1)
+
+
+@pytest.mark.parametrize("dim,batch,params", [(128, 100, {"wide_rows": 1000}), (64, 37, {"wide_rows": 370, "hub_fanin": 4}), (16, 64, {"wide_rows": 512})])
+def test_plans_built_on_several_host_threads_are_the_serial_ones(rmat, dim, batch, params):
+    """wide_plans_for_epoch: the plans of an epoch are independent of each other and are built side by side on host threads, then appended
+    in launch order -- the resident arrays (items, jobs, workgroup descriptors, tree nodes) are byte for byte the serial build's, and
+    the checker passes on them."""
+    rowptr, colids = rmat
+    serial = check(rowptr, colids, dim, batch, **params)
+    for threads in (2, 5):
+        assert check(rowptr, colids, dim, batch, plan_threads=threads, **params) == serial
+    walk = check(rowptr, colids, dim, batch, walk=1, **params)
+    assert check(rowptr, colids, dim, batch, walk=1, plan_threads=3, **params) == walk
 
 
 def test_wide_plan_check_sees_a_broken_plan_shape():
