@@ -56,6 +56,17 @@ struct Plan {
     uint64_t compulsory = 0;  // bytes this launch must move even with perfect caching inside the launch ("count_compulsory")
 };
 
+// The resident plan arrays reach gigabytes (RMAT-24 at batch 384: 2.9 GB) and are filled by memcpy from the parts the host's threads
+// built: resize() must not zero them first (one thread, page by page) -- an allocator whose construct() of no arguments default-initialises.
+template <class T>
+struct RawInit : std::allocator<T> {
+    template <class U> struct rebind { using other = RawInit<U>; };
+    using std::allocator<T>::allocator;
+    template <class U> void construct(U *p) noexcept { ::new (static_cast<void *>(p)) U; }
+    template <class U, class... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+};
+template <class T> using PlanVec = std::vector<T, RawInit<T>>;
+
 struct SeenScratch {  // "count_compulsory": has this row been counted in this minibatch?  One stamp per vertex (a plan-building thread owns one)
     std::vector<uint32_t> seen;
     uint32_t stamp = 0;
@@ -154,8 +165,8 @@ struct f2v_ctx {
     size_t d_wg_cap = 0, d_wg_valid = 0;
     // ... in the wide form ("chain_wide", the default where the fan-in allows it): workgroup programs and their jobs
     std::map<std::tuple<uint32_t, uint32_t, uint32_t, int>, WidePlan> wides;
-    std::vector<WideDesc> h_wide;
-    std::vector<WJob> h_jobs;
+    PlanVec<WideDesc> h_wide;
+    PlanVec<WJob> h_jobs;
     WideDesc *d_wide = nullptr;
     WJob *d_jobs = nullptr;
     size_t d_wide_cap = 0, d_wide_valid = 0, d_jobs_cap = 0, d_jobs_valid = 0;
@@ -184,8 +195,8 @@ struct f2v_ctx {
     uint32_t *d_rowflag = nullptr;  // per row: sequence number of the chained launch that last wrote it
     bool chain = true;            // "chain_batches"
     uint32_t chain_max_batch = 4096, chain_rows = 65536;  // measured on RMAT-20 (tools/small_batch.py, tools/chain_sweep.py)
-    std::vector<Item> h_items;
-    std::vector<FinItem> h_hubs;
+    PlanVec<Item> h_items;
+    PlanVec<FinItem> h_hubs;
     Item *d_items = nullptr;
     FinItem *d_hubs = nullptr;
     size_t d_items_cap = 0, d_hubs_cap = 0, d_items_valid = 0, d_hubs_valid = 0;
@@ -1039,6 +1050,8 @@ void wide_plans_for_epoch(f2v_ctx *c, uint32_t nb, uint32_t K, uint32_t batch, b
         for (uint32_t b0 : todo) (void)wide_plan_for(c, b0, std::min(K, nb - b0), batch, walk);
         return;
     }
+    const bool timing = getenv("F2V_PLAN_TIMING") != nullptr;  // (measurements: where the first call of a batch size spends its host time)
+    const auto t_0 = std::chrono::steady_clock::now();
     std::vector<WideParts> parts(todo.size());
     std::vector<WidePlan> plans(todo.size());
     std::atomic<size_t> next{0};
@@ -1050,9 +1063,51 @@ void wide_plans_for_epoch(f2v_ctx *c, uint32_t nb, uint32_t K, uint32_t batch, b
                 plans[k] = build_wide_plan(c, todo[k], std::min(K, nb - todo[k]), batch, walk, parts[k], seen);
         });
     for (auto &y : th) y.join();
+    const auto t_1 = std::chrono::steady_clock::now();
+    // the resident arrays get their final size once (no regrowth copies), the parts are moved in by the threads -- side by side: every
+    // part has its place (prefix sums of the sizes), and a part is released as soon as it has been copied
+    std::vector<size_t> at_items(todo.size() + 1, c->h_items.size()), at_jobs(todo.size() + 1, c->h_jobs.size()), at_wide(todo.size() + 1, c->h_wide.size()),
+        at_hubs(todo.size() + 1, c->h_hubs.size());
     for (size_t k = 0; k < todo.size(); k++) {
-        (void)wide_plan_append(c, todo[k], std::min(K, nb - todo[k]), batch, walk, plans[k], parts[k]);
-        parts[k] = WideParts{};  // (release as we go: the parts are a second copy of the epoch's plans)
+        at_items[k + 1] = at_items[k] + parts[k].items.size();
+        at_jobs[k + 1] = at_jobs[k] + parts[k].jobs.size();
+        at_wide[k + 1] = at_wide[k] + parts[k].wide.size();
+        at_hubs[k + 1] = at_hubs[k] + parts[k].hubs.size();
+    }
+    c->h_items.resize(at_items.back());
+    c->h_jobs.resize(at_jobs.back());
+    c->h_wide.resize(at_wide.back());
+    c->h_hubs.resize(at_hubs.back());
+    const auto t_2 = std::chrono::steady_clock::now();
+    next = 0;
+    th.clear();
+    for (unsigned t = 0; t < T; t++)
+        th.emplace_back([&] {
+            for (size_t k; (k = next.fetch_add(1)) < todo.size();) {
+                WideParts &q = parts[k];
+                if (!q.items.empty()) memcpy(c->h_items.data() + at_items[k], q.items.data(), q.items.size() * sizeof(Item));
+                if (!q.jobs.empty()) memcpy(c->h_jobs.data() + at_jobs[k], q.jobs.data(), q.jobs.size() * sizeof(WJob));
+                if (!q.wide.empty()) memcpy(c->h_wide.data() + at_wide[k], q.wide.data(), q.wide.size() * sizeof(WideDesc));
+                if (!q.hubs.empty()) memcpy(c->h_hubs.data() + at_hubs[k], q.hubs.data(), q.hubs.size() * sizeof(FinItem));
+                q = WideParts{};
+            }
+        });
+    for (auto &y : th) y.join();
+    for (size_t k = 0; k < todo.size(); k++) {
+        WidePlan &p = plans[k];
+        p.item_off = at_items[k];
+        p.job_off = at_jobs[k];
+        p.wg_off = at_wide[k];
+        p.fin_off = at_hubs[k];
+        if (p.n_slots > kItemSlotMask || (uint64_t)p.n_slots * c->D * sizeof(float) > 0xFFFFFFFFull) c->plan_overflow = true;
+        c->max_slots = std::max<size_t>(c->max_slots, p.n_slots);
+        c->wides.emplace(std::make_tuple(todo[k], std::min(K, nb - todo[k]), batch, walk ? 1 : 0), p);
+    }
+    if (timing) {
+        const auto t_3 = std::chrono::steady_clock::now();
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "f2v plan timing: %zu plans on %u threads: built %.0f ms, resident arrays sized %.0f ms, parts moved in %.0f ms (%.1f MB of items)\n", todo.size(), T, ms(t_0, t_1), ms(t_1, t_2),
+                ms(t_2, t_3), c->h_items.size() * sizeof(Item) / 1e6);
     }
 }
 
@@ -1070,6 +1125,7 @@ int upload_plans(f2v_ctx *c) {
         c->h_wide.size() == c->d_wide_valid && c->h_jobs.size() == c->d_jobs_valid && !grow_slots)
         return F2V_OK;  // O(1) steady state
     HIPC(hipStreamSynchronize(c->stream));  // launches in flight read these buffers
+    const auto t_up0 = std::chrono::steady_clock::now();
     if (c->h_wide.size() > c->d_wide_cap) {
         if (c->d_wide) (void)hipFree(c->d_wide);
         c->d_wide = nullptr;
@@ -1135,6 +1191,8 @@ int upload_plans(f2v_ctx *c) {
                        (c->h_hubs.size() - c->d_hubs_valid) * sizeof(FinItem), hipMemcpyHostToDevice));
     c->d_items_valid = c->h_items.size();
     c->d_hubs_valid = c->h_hubs.size();
+    if (getenv("F2V_PLAN_TIMING"))
+        fprintf(stderr, "f2v plan timing: upload %.0f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_up0).count());
     return F2V_OK;
 }
 

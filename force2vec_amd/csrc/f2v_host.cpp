@@ -145,35 +145,59 @@ void sm_table_host(float *t) {
 // last (ONE rand() draw); degree 2: the first neighbour; otherwise colids[w] with the VERTEX id as edge index (kept for parity,
 // clamped to the array) -- each step's target is a sample and the next step's start.  rand() is drawn only at vertices of
 // degree > 2, so where a walk's draws lie in the stream depends on every walk before it: the reference's loop is one chain of
-// dependent cache misses (35 ns a step on RMAT-20).  Here 32 consecutive walks run side by side, step by step, every access
-// prefetched a pass ahead, from stream positions PREDICTED for them (a draw at every step but those whose degree is known
-// beforehand: the start vertex, and the second vertex where the first step draws nothing); afterwards the draws each walk really
-// made are compared with the prediction, the walks up to and including the first mispredicted one are kept -- they started at
-// the right position -- and the next block, as long as the stretch that held (doubling again while all hold), starts behind it.  Same samples, same stream position afterwards (draws taken ahead are
-// given back, Rand::back), whatever the graph.
-#ifndef F2V_WALK_BLOCK
-#define F2V_WALK_BLOCK 32  // RMAT-20, 5.2 M steps: 8 / 16 / 32 / 64 / 128 walks side by side -> 210 / 178 / 168 / 205 / 350 ms where the serial loop takes 530
-#endif
+// dependent cache misses (35 ns a step on RMAT-20).
+//
+// Here up to 64 consecutive walks are IN FLIGHT, each at its own step, from stream positions PREDICTED for them (a draw at every step
+// but the first of a walk that starts at a vertex of degree <= 2, which is known beforehand); one pass over the walks in flight
+// computes every one's next edge index (and prefetches it), a second pass reads the targets (and prefetches their row pointers).  A
+// walk that reaches a vertex of degree <= 2 where a draw was predicted has drawn one number fewer than the younger walks in flight
+// assumed: they -- and only they -- are dropped and issued again behind it, from the corrected position.  On RMAT-20 that happens to
+// one walk in 32 (tools/walk_deficits.py), and the younger walks have by then taken a step or two each: round 3's blocks of 32
+// (all walks step by step together, validated when the block was done, everything behind the first mispredicted walk thrown away and
+// the block boundary drained) lost ~38 % of their work, this loses ~12 %.  Same samples, same stream position afterwards (draws taken
+// ahead are given back, Rand::back), whatever the graph; where more than one walk in three is mispredicted (cora: half the steps draw
+// nothing, and the graph sits in the cache) the reference's own serial loop runs, 64 walks at a time.
 void walks_host(Rand &g, const uint32_t *rp, const uint32_t *ci, uint32_t n, uint64_t nnz, uint32_t *walks) {
-    constexpr uint32_t B = F2V_WALK_BLOCK, L = (uint32_t)kWalkLength, V = B * L;
+    constexpr uint32_t L = (uint32_t)kWalkLength, SMAX = 64, RING = 1024, MASK = RING - 1;
+    static_assert(RING >= 2 * SMAX * L && (RING & MASK) == 0, "the ring holds every draw a walk in flight may ask for");
     if (nnz == 0) {  // no vertex has a neighbour: nothing is drawn (the reference would read colids[0] of an empty array)
         for (size_t k = 0; k < (size_t)n * L; k++) walks[k] = 0;
         return;
     }
     const uint32_t last = (uint32_t)(nnz - 1);
-    uint32_t vals[V];
-    uint32_t avail = 0;  // vals[0, avail): the stream's next draws
-    uint32_t w[B], jj[B], off[B], used[B], predicted[B];
-    // How many walks run side by side follows how often the predictions have been failing: fewer than one walk in four (RMAT-20: one
-    // in 25) -> a full block, the memory latency is what there is to hide; more than one in two (cora: half the steps draw nothing, and
-    // the graph sits in the cache) -> the reference's own serial loop, 64 walks at a time, which no block of doomed walks beats.
-    uint32_t width = B, seen = 0, missed = 0;
-    for (uint32_t i0 = 0; i0 < n;) {
-        if (width == 1u) {
-            while (avail) { g.back(); avail--; }
-            const uint32_t stop = std::min(n, i0 + 64u);
-            for (; i0 < stop; i0++) {
-                uint32_t v = i0, draws = 0;
+    uint32_t ring[RING];
+    uint64_t gen = 0;       // draws taken from g so far: ring[k & MASK] is draw k for gen - RING <= k < gen
+    uint64_t next_off = 0;  // the stream position predicted for the next walk to be issued (exact once nothing is in flight)
+    struct Slot { uint64_t base; uint32_t i, v, j; uint8_t s, used, pred; };  // base: the stream position of the walk's first draw
+    Slot sl[SMAX];
+    uint32_t head = 0, count = 0, next_i = 0;
+    // how many walks are in flight follows how often the predictions have been failing
+    // (at most a quarter of them are issued per pass, so that the walks in flight stay staggered over the five steps: a walk that
+    // mispredicts at its step s then finds the younger ones at steps below s, not all at s.  RMAT-20, build container, ms per epoch:
+    // round 3's blocks 175-183; 32 in flight 156-170; 48 / 64 in flight, 12 ... 20 issued per pass 141-152; with the true
+    // positions given (nothing ever dropped: the bound of any one-thread scheme) 96-107)
+    uint32_t width = 32, issue_cap = 8, seen = 0, missed = 0;
+    const char *fixed = getenv("F2V_WALKS_IN_FLIGHT");  // (measurements: a fixed number of walks in flight, F2V_WALKS_ISSUE per pass)
+    if (fixed) {
+        width = std::max(1u, std::min<uint32_t>((uint32_t)atoi(fixed), SMAX));
+        issue_cap = std::max(1u, width / 4u);
+        if (const char *e = getenv("F2V_WALKS_ISSUE")) issue_cap = std::max(1u, (uint32_t)atoi(e));
+    }
+    auto adapt = [&] {
+        if (seen >= 512u) { seen >>= 1; missed >>= 1; }
+        if (fixed) return;
+        // fewer than one walk in 24 mispredicted -> 64 in flight (the memory latency is what there is to hide); up to one in three ->
+        // about one run's worth; beyond that the serial loop
+        width = 24u * missed <= seen ? SMAX : 3u * missed <= seen ? std::max(4u, std::min(32u, seen / std::max(missed, 1u))) : 1u;
+        issue_cap = std::max(2u, width / 4u);
+    };
+    while (next_i < n || count) {
+        if (width == 1u && count == 0u) {
+            // the reference's serial loop, 64 walks at a time (draws straight from the generator: give back what was taken ahead)
+            while (gen > next_off) { g.back(); gen--; }
+            const uint32_t stop = std::min(n, next_i + 64u);
+            for (; next_i < stop; next_i++) {
+                uint32_t v = next_i, draws = 0;
                 for (uint32_t s = 0; s < L; s++) {
                     const uint32_t lo = rp[v], deg = rp[v + 1] - lo;
                     uint32_t j = v;
@@ -181,68 +205,70 @@ void walks_host(Rand &g, const uint32_t *rp, const uint32_t *ci, uint32_t n, uin
                     else if (deg == 2) j = lo;
                     if (j > last) j = last;
                     v = ci[j];
-                    walks[(size_t)i0 * L + s] = v;
+                    walks[(size_t)next_i * L + s] = v;
                 }
+                gen += draws;
+                next_off += draws;
                 seen++;
-                missed += draws < L - 1u ? 1u : 0u;  // (what a block would have mispredicted, more or less: a step past the first drew nothing)
+                missed += draws < L - 1u ? 1u : 0u;  // (what would have been mispredicted, more or less: a step past the first drew nothing)
             }
-            if (seen >= 512u) { seen >>= 1; missed >>= 1; }
-            width = 4u * missed <= seen ? B : 2u * missed <= seen ? 4u : 1u;
+            adapt();
             continue;
         }
-        const uint32_t nb = std::min(width, n - i0);
-        while (avail < nb * L) vals[avail++] = (uint32_t)g.next();
-        // predicted draws per walk
-        for (uint32_t t = 0; t < nb; t++) {
-            const uint32_t i = i0 + t, deg = rp[i + 1] - rp[i];
-            w[t] = i;
-            used[t] = 0;
+        // issue walks up to the width
+        uint32_t issued = 0;
+        while (count < width && next_i < n && issued++ < issue_cap) {
+            Slot &x = sl[(head + count) % SMAX];
+            x.i = x.v = next_i;
+            x.s = x.used = 0;
+            x.base = next_off;
+            x.pred = (uint8_t)(rp[next_i + 1] - rp[next_i] > 2 ? L : L - 1u);
+            next_off += x.pred;
+            next_i++;
+            count++;
+        }
+        while (gen < next_off) { ring[gen & MASK] = (uint32_t)g.next(); gen++; }
+        // pass 1: every walk's next edge index
+        for (uint32_t k = 0; k < count; k++) {
+            Slot &x = sl[(head + k) % SMAX];
+            const uint32_t v = x.v, lo = rp[v], deg = rp[v + 1] - lo;
+            uint32_t j = v;
             if (deg > 2) {
-                predicted[t] = L;
-                jj[t] = 0xFFFFFFFFu;
+                j = ring[(x.base + x.used) & MASK] % (deg - 1) + lo;  // randIndex(rowptr[v+1] - 1, rowptr[v])
+                x.used++;
             } else {
-                const uint32_t j = std::min(deg == 2 ? rp[i] : i, last);
-                jj[t] = ci[j];  // the second vertex, known without a draw
-                __builtin_prefetch(rp + jj[t]);
+                if (deg == 2) j = lo;
+                if (x.s != 0) {
+                    // a draw was predicted here: this walk takes one number fewer than the younger walks in flight assumed -- they go
+                    // back to the queue, behind the corrected position
+                    x.pred--;
+                    missed++;
+                    next_i = x.i + 1;
+                    next_off = x.base + x.pred;
+                    count = k + 1;
+                }
             }
+            if (j > last) j = last;
+            x.j = j;
+            __builtin_prefetch(ci + j);
         }
-        uint32_t at = 0;
-        for (uint32_t t = 0; t < nb; t++) {
-            if (jj[t] != 0xFFFFFFFFu) predicted[t] = (L - 2) + (rp[jj[t] + 1] - rp[jj[t]] > 2 ? 1u : 0u);
-            off[t] = at;
-            at += predicted[t];
+        // pass 2: the targets
+        for (uint32_t k = 0; k < count; k++) {
+            Slot &x = sl[(head + k) % SMAX];
+            const uint32_t v = ci[x.j];
+            walks[(size_t)x.i * L + x.s] = v;
+            x.v = v;
+            x.s++;
+            __builtin_prefetch(rp + v);
         }
-        for (uint32_t s = 0; s < L; s++) {
-            for (uint32_t t = 0; t < nb; t++) {
-                const uint32_t v = w[t], lo = rp[v], deg = rp[v + 1] - lo;
-                uint32_t j = v;
-                if (deg > 2) j = vals[off[t] + used[t]++] % (deg - 1) + lo;  // randIndex(rowptr[v+1] - 1, rowptr[v])
-                else if (deg == 2) j = lo;
-                if (j > last) j = last;
-                jj[t] = j;
-                __builtin_prefetch(ci + j);
-            }
-            for (uint32_t t = 0; t < nb; t++) {
-                const uint32_t v = ci[jj[t]];
-                walks[(size_t)(i0 + t) * L + s] = v;
-                w[t] = v;
-                __builtin_prefetch(rp + v);
-            }
+        while (count && sl[head].s == L) {  // (walks finish in the order they were issued)
+            head = (head + 1) % SMAX;
+            count--;
+            seen++;
         }
-        uint32_t valid = nb, consumed = 0;
-        for (uint32_t t = 0; t < nb; t++) {
-            consumed += used[t];
-            if (used[t] != predicted[t]) { valid = t + 1; break; }
-        }
-        avail -= consumed;
-        memmove(vals, vals + consumed, avail * sizeof(uint32_t));
-        i0 += valid;
-        seen += valid;
-        missed += valid < nb ? 1u : 0u;
-        if (seen >= 512u) { seen >>= 1; missed >>= 1; }
-        width = 4u * missed <= seen ? B : 2u * missed <= seen ? 4u : 1u;
+        adapt();
     }
-    while (avail--) g.back();
+    while (gen > next_off) { g.back(); gen--; }
 }
 
 }  // namespace f2v

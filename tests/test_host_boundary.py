@@ -376,9 +376,16 @@ def _walk_graphs():
     yield "k4", (3 * np.arange(5)).astype(np.uint32), np.array([1, 2, 3, 0, 2, 3, 0, 1, 3, 0, 1, 2], dtype=np.uint32)
 
 
-def test_walks_from_the_rand_stream_equal_the_reference_loop():
-    """f2v_rng_walks (32 walks side by side from predicted stream positions) = the oracle's serial loop (algorithms.cpp:1097-1118):
-    same samples, and the stream stands where the serial loop leaves it -- two epochs in a row, several seeds."""
+@pytest.mark.parametrize("in_flight", [None, "1", "3", "7", "64"])
+def test_walks_from_the_rand_stream_equal_the_reference_loop(in_flight, monkeypatch):
+    """f2v_rng_walks (up to 64 walks in flight, each at its own step, from predicted stream positions; the younger ones issued again behind
+    a walk that drew fewer numbers than predicted) = the oracle's serial loop (algorithms.cpp:1097-1118): same samples, and the stream
+    stands where the serial loop leaves it -- two epochs in a row, several seeds; with the adaptive number of walks in flight and with
+    fixed ones (F2V_WALKS_IN_FLIGHT: 1 = the serial loop itself, odd widths, the maximum)."""
+    if in_flight is None:
+        monkeypatch.delenv("F2V_WALKS_IN_FLIGHT", raising=False)
+    else:
+        monkeypatch.setenv("F2V_WALKS_IN_FLIGHT", in_flight)
     L = _lib.lib()
     for name, rp, ci in _walk_graphs():
         n = len(rp) - 1

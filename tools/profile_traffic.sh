@@ -9,7 +9,7 @@ BATCH=${1:-65536}; SCALE=${2:-20}; DIM=${3:-128}; OPTION=${4:-5}
 P=$R/gpurun_out/prof
 rm -rf $P && mkdir -p $P
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --settle-ms 0 --extra-batches= --config5-scale 0 --config4 0 --cora 0 --sustained-s 0 --verify-rows 0 --batch $BATCH --scale $SCALE --dim $DIM --option $OPTION"
+BENCH="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --settle-ms 0 --extra-batches= --config5-scale 0 --config4 0 --cora 0 --sustained-s 0 --live-pmc 0 --option7 0 --verify-rows 0 --batch $BATCH --scale $SCALE --dim $DIM --option $OPTION"
 pass() {  # name, counters...
   local name=$1; shift
   rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $P/pmc_$name -- $BENCH > $P/pmc_$name.json 2> $P/pmc_$name.err
