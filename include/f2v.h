@@ -88,7 +88,7 @@ F2V_API int f2v_get_embeddings(f2v_handle h, float *x_out);
  * one launch -- a ring of matrices, epoch e reads matrix e and writes matrix e + 1 behind its own row flags; same results, and what was a
  * launch boundary per epoch becomes one more hop of the dependency chain ("last_wide_epochs" answers what the last f2v_train did);
  * "wide_samples_early" (-1 = automatic: small graphs): the sample rows a launch itself writes are awaited before
- * the first neighbour waits instead of after them (placement in time only); "last_train_form" answers how the last f2v_train launched (0 one launch per minibatch, 1 chained, 2 wide), "last_wide_width"
+ * the first neighbour waits instead of after them (placement in time only); "last_train_form" answers how the last f2v_train launched (0 one launch per minibatch, 1 chained, 2 wide, 3 hipGraph replay: set where the launches are made), "last_wide_width"
  * the sub-wave layout a wide run used, "last_wide_early" whether it ran the kernel's EARLY form; "class_cut" (default 1): a split row's pieces also end where its ascending neighbour ids cross
  * from one eighth of the id range into the next (part of the summation order, restated by the oracle; it is what makes
  * "piece_affinity" pure); "piece_affinity" (default 1): a split row's pieces run on the XCD that owns
@@ -97,6 +97,11 @@ F2V_API int f2v_get_embeddings(f2v_handle h, float *x_out);
  * kernel for every D; "waves_per_block"; "rows_in_flight" (0 = the kernels' default | 4 | 8); "use_graph" = 1 makes f2v_train replay a
  * captured hipGraph per epoch instead of launching eagerly (same results; measured no faster); "count_compulsory" = 1
  * makes new launch plans count their compulsory bytes (f2v_stats.compulsory_bytes).
+ * Launch plans: the first f2v_train of a batch size builds the epoch's plans on the host (the wide form's on the host's threads:
+ * F2V_IO_THREADS bounds them; RMAT-24 at batch 384: 65 plans, 0.8 s) and keeps them resident on the host and in HBM -- "plan_resident_bytes"
+ * answers how much (RMAT-20 at batch 256: 184 MB; RMAT-24 at batch 384: 2.9 GB); the cache holds up to three epochs' worth of items and is
+ * dropped and rebuilt on demand beyond that (a run that alternates many batch sizes).  "wide_single" = 1 (measurement only) lets the wide form run
+ * launches of one minibatch.
  * Sharded runs: "push_fused" (default 1: the step kernels push their rows themselves, 0: a kernel behind
  * them does), "push_timeout_ms".
  * "fast_rng" = 1 selects the NON-PARITY fast mode: initial embeddings and the option-7

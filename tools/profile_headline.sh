@@ -3,5 +3,5 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/final2
 rm -rf $O && mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/k65536 -- python3 $R/bench.py --no-cpu-baseline --extra-batches= --config5-scale 0 --config4 0 --cora 0 --sustained-s 0 --live-pmc 0 --option7 0 > $O/bench_65536_profiled.json 2> $O/bench_65536.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/k65536 -- python3 $R/bench.py --no-cpu-baseline --extra-batches= --config5-scale 0 --config4 0 --cora 0 --sustained-s 0 --live-pmc 0 --option7 0 --verify-rows 0 > $O/bench_65536_profiled.json 2> $O/bench_65536.err
 head -2 $O/k65536/*/*_kernel_stats.csv | cut -c1-200
