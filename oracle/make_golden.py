@@ -137,6 +137,17 @@ def longrun_sections(manifest):
             manifest[key] = {"%.2f" % k: {"micro": v[0], "macro": v[1]} for k, v in f1.items()}
             manifest[key]["md5"] = md5
             print(key, manifest[key])
+    # the clustering half of the reference's scorer (runnodeclassclust.py:311-331): KMeans + modularity of its OWN 1200-epoch option-5
+    # embedding of cora (the md5-pinned F1 run), seeded restatement in tests/cluster_harness.py
+    import cluster_harness as CH
+    with tempfile.TemporaryDirectory() as td:
+        path, _ = O.run_reference(os.path.join(REF_INPUT, "cora.mtx"), td, 5, 1200, 256, 128, threads=1)
+        md5 = hashlib.md5(open(path, "rb").read()).hexdigest()
+        assert md5 == pinned["cora_opt5_it1200_B256_D128_bs0"]["md5"], "the reference run differs from the manifest's pinned md5"
+        rp, ci = O.read_mtx(os.path.join(REF_INPUT, "cora.mtx"))
+        tab = CH.modularity_table(O.read_embd(path), rp, ci)
+        manifest["modularity_reference_cora_opt5_it1200_B256_D128"] = {"md5": md5, "table": {str(k): v for k, v in tab.items()}}
+        print("modularity", tab)
     with tempfile.TemporaryDirectory() as td:
         path, _ = O.run_reference(os.path.join(REF_INPUT, "cora.mtx"), td, 5, 100, 256, 128, threads=1)
         md5 = hashlib.md5(open(path, "rb").read()).hexdigest()

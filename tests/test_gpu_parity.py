@@ -242,12 +242,26 @@ def test_train_recovers_from_a_lost_launch(F, option, batch, bs):
         res.append(eng.get_embeddings())
         assert eng.get_param("recoveries") == (1 if fault else 0)
         assert eng.get_param("merge_finalize") == (0 if fault else 1)
+        st = eng.stats()
+        assert st["recoveries"] == (1 if fault else 0) and st["recovered"] == (1 if fault else 0) and st["merge_finalize"] == (0 if fault else 1)
+        assert st["snapshot_seconds"] > 0.0  # (the snapshot copy of "recover": timed on its own, outside device_seconds)
         if fault:
             assert "recovered" in T.f2v_last_error().decode()
             eng.train(option, 2, batch, 5, 0.02, bs)                 # the handle goes on, without in-grid waits
             assert eng.get_param("recoveries") == 1 and np.isfinite(eng.get_embeddings()).all()
+            assert eng.stats()["recovered"] == 0 and eng.get_param("merge_finalize") == 0
+            # the fault gone, the in-grid waits come back by themselves after the first healthy call (then after 2, 4 ... 64)
+            _lib.check(T.f2v_test_withhold_flag(eng._h, 0xFFFFFFFF), T)
+            _lib.check(T.f2v_test_withhold_row(eng._h, 0xFFFFFFFF), T)
+            eng.train(option, 2, batch, 5, 0.02, bs)
+            assert eng.get_param("merge_finalize") == 1 and eng.get_param("recoveries") == 1 and eng.stats()["recovered"] == 0
+            extra = eng.get_embeddings()
+        else:
+            eng.train(option, 4, batch, 5, 0.02, bs)
+            healthy_extra = eng.get_embeddings()
         eng.close()
     assert np.array_equal(res[0], res[1]) and np.isfinite(res[0]).all()
+    assert np.array_equal(healthy_extra, extra)  # (44 epochs either way: slow forms, fast forms, the same bits)
 
 
 def test_two_handles_training_at_once_share_the_card_safely(F):
@@ -1076,6 +1090,24 @@ def test_cora_f1_within_half_point_of_reference(F, manifest):
         assert abs(mic - r["micro"]) <= 0.5, (tf, mic, r["micro"])
         assert abs(mac - r["macro"]) <= 0.75, (tf, mac, r["macro"])
     algo.engine.close()
+
+
+def test_cora_clustering_modularity_level_with_the_reference(F, manifest):
+    """The other half of the reference's scorer (runnodeclassclust.py:311-331): KMeans on the embedding per cluster count, modularity of each
+    clustering on the graph.  Option 5, 1200 epochs on the GPU against the table of the reference's OWN embedding (manifest
+    modularity_reference_cora_opt5_it1200_B256_D128; seeded restatement tests/cluster_harness.py): every cluster count within 0.02, the
+    best modularity within 0.01 (measured between the reference's order and the kernels': <= 0.006)."""
+    import cluster_harness as CH
+    rowptr, colids = F.read_mtx(golden_graph_path("cora.mtx"))
+    algo = F.algorithms((rowptr, colids), dim=128)
+    algo.srand(1)
+    algo._run(5, 0, 1200, 256, 5, 0.02, write=False)
+    ref = {int(k): v for k, v in manifest["modularity_reference_cora_opt5_it1200_B256_D128"]["table"].items()}
+    got = CH.modularity_table(algo.nCoordinates, rowptr, colids, cluster_counts=tuple(ref))
+    algo.engine.close()
+    for c in ref:
+        assert abs(got[c] - ref[c]) <= 0.02, (c, got[c], ref[c])
+    assert abs(max(got.values()) - max(ref.values())) <= 0.01, (got, ref)
 
 
 @pytest.mark.parametrize("option", [6, 7])
