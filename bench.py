@@ -665,8 +665,9 @@ def main():
                        "need": "%s all-to-all-v of the rows each rank reads" % ("RCCL" if args.dist_backend == "nccl" else "gloo (host-bounce self-test)")}[state["exchange"]])},
     }
     if st is not None:
-        res["config"]["recoveries"] = int(st.get("recoveries", 0))          # give-ups f2v_train recovered from on this handle so far (0 expected)
-        res["config"]["merge_finalize"] = int(st.get("merge_finalize", 1))  # 0: the handle has fallen back to launches without in-grid waits
+        now = eng.stats()  # (the handle's own answers: a sharded run's `st` holds differences)
+        res["config"]["recoveries"] = int(now.get("recoveries", 0))          # give-ups f2v_train recovered from on this handle so far (0 expected)
+        res["config"]["merge_finalize"] = int(now.get("merge_finalize", 1))  # 0: the handle has fallen back to launches without in-grid waits
         if not use_dist:
             res["config"]["snapshot_copy_ms_per_train_call"] = st.get("snapshot_seconds", 0.0) * 1e3  # "recover": outside ms_per_step's device time, inside the wall time
     if use_dist:
