@@ -479,18 +479,40 @@ int f2v_write_embd(const char *path, const float *x, uint32_t n, uint32_t dim) {
     if (!path || !x) return fail(F2V_EINVAL, "f2v_write_embd: null argument");
     FILE *fp = fopen(path, "wb");
     if (!fp) return fail(F2V_EIO, "f2v_write_embd: cannot open %s: %s", path, strerror(errno));
-    std::vector<char> line((size_t)dim * 16 + 32);
     fprintf(fp, "%u %u\n", n, dim);
-    for (uint32_t i = 0; i < n; i++) {
-        char *q = line.data();
-        q += sprintf(q, "%u ", i + 1);
-        const float *row = x + (size_t)i * dim;
-        for (uint32_t d = 0; d < dim; d++) q += sprintf(q, "%g ", (double)row[d]);
-        *q++ = '\n';
-        if (fwrite(line.data(), 1, (size_t)(q - line.data()), fp) != (size_t)(q - line.data())) {
-            fclose(fp);
-            return fail(F2V_EIO, "f2v_write_embd: short write to %s", path);
+    // The text is what `out << value << " "` writes (six significant digits: %g), row by row -- and formatting IS the cost: 134 M values
+    // for RMAT-20 at D = 128, ~20 s on one thread, more than 1200 epochs of training take.  Rows are formatted by the host's threads
+    // (F2V_IO_THREADS) in slices of a few thousand rows, a round of slices at a time, and written in order: the same bytes.
+    unsigned T = std::thread::hardware_concurrency();
+    if (const char *e = getenv("F2V_IO_THREADS")) T = (unsigned)atoi(e);
+    T = std::max(1u, std::min(T, 64u));
+    if ((uint64_t)n * dim < (1u << 20)) T = 1;
+    const uint32_t slice = std::max<uint32_t>(1u, (uint32_t)std::min<uint64_t>(4096, (4ull << 20) / std::max<uint64_t>((uint64_t)dim * 12, 1)));  // ~4 MB of text per slice
+    auto format = [&](uint32_t lo, uint32_t hi, std::vector<char> &buf) {
+        buf.resize((size_t)(hi - lo) * ((size_t)dim * 16 + 16));
+        char *q = buf.data();
+        for (uint32_t i = lo; i < hi; i++) {
+            q += sprintf(q, "%u ", i + 1);
+            const float *row = x + (size_t)i * dim;
+            for (uint32_t d = 0; d < dim; d++) q += sprintf(q, "%g ", (double)row[d]);
+            *q++ = '\n';
         }
+        buf.resize((size_t)(q - buf.data()));
+    };
+    std::vector<std::vector<char>> bufs(T);
+    bool ok = true;
+    for (uint64_t base = 0; base < n && ok; base += (uint64_t)T * slice) {
+        const unsigned live = (unsigned)std::min<uint64_t>(T, (n - base + slice - 1) / slice);
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < live; t++)
+            th.emplace_back([&, t] { format((uint32_t)(base + (uint64_t)t * slice), (uint32_t)std::min<uint64_t>(n, base + (uint64_t)(t + 1) * slice), bufs[t]); });
+        format((uint32_t)base, (uint32_t)std::min<uint64_t>(n, base + slice), bufs[0]);
+        for (auto &y : th) y.join();
+        for (unsigned t = 0; t < live && ok; t++) ok = fwrite(bufs[t].data(), 1, bufs[t].size(), fp) == bufs[t].size();
+    }
+    if (!ok) {
+        fclose(fp);
+        return fail(F2V_EIO, "f2v_write_embd: short write to %s", path);
     }
     if (fclose(fp) != 0) return fail(F2V_EIO, "f2v_write_embd: close failed for %s", path);
     return F2V_OK;
