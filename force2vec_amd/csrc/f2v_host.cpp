@@ -16,8 +16,6 @@
 #include <thread>
 #include <vector>
 
-#include <unistd.h>
-
 #include "f2v.h"
 #include "f2v_internal.h"
 
@@ -501,41 +499,18 @@ int f2v_write_embd(const char *path, const float *x, uint32_t n, uint32_t dim) {
         }
         buf.resize((size_t)(q - buf.data()));
     };
-    // (the header went through stdio; the rows go through the descriptor: every thread writes its own slice at the slice's place in
-    // the file -- the copies into the page cache run side by side too, a single writer was half of the time)
-    if (fflush(fp) != 0) { fclose(fp); return fail(F2V_EIO, "f2v_write_embd: short write to %s", path); }
-    const int fd = fileno(fp);
-    off_t at = ftello(fp);
     std::vector<std::vector<char>> bufs(T);
-    std::atomic<bool> ok{true};
-    for (uint64_t base = 0; base < n && ok.load(); base += (uint64_t)T * slice) {
+    bool ok = true;
+    for (uint64_t base = 0; base < n && ok; base += (uint64_t)T * slice) {
         const unsigned live = (unsigned)std::min<uint64_t>(T, (n - base + slice - 1) / slice);
-        auto rows_of = [&](unsigned t, uint32_t &lo, uint32_t &hi) {
-            lo = (uint32_t)(base + (uint64_t)t * slice);
-            hi = (uint32_t)std::min<uint64_t>(n, base + (uint64_t)(t + 1) * slice);
-        };
-        auto parallel = [&](auto &&fn) {
-            std::vector<std::thread> th;
-            for (unsigned t = 1; t < live; t++) th.emplace_back(fn, t);
-            fn(0u);
-            for (auto &y : th) y.join();
-        };
-        parallel([&](unsigned t) { uint32_t lo, hi; rows_of(t, lo, hi); format(lo, hi, bufs[t]); });
-        std::vector<off_t> where(live + 1, at);
-        for (unsigned t = 0; t < live; t++) where[t + 1] = where[t] + (off_t)bufs[t].size();
-        parallel([&](unsigned t) {
-            const char *q = bufs[t].data();
-            size_t left = bufs[t].size();
-            off_t o = where[t];
-            while (left) {
-                const ssize_t w = pwrite(fd, q, left, o);
-                if (w <= 0) { if (w < 0 && errno == EINTR) continue; ok.store(false); return; }
-                q += w; left -= (size_t)w; o += w;
-            }
-        });
-        at = where[live];
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < live; t++)
+            th.emplace_back([&, t] { format((uint32_t)(base + (uint64_t)t * slice), (uint32_t)std::min<uint64_t>(n, base + (uint64_t)(t + 1) * slice), bufs[t]); });
+        format((uint32_t)base, (uint32_t)std::min<uint64_t>(n, base + slice), bufs[0]);
+        for (auto &y : th) y.join();
+        for (unsigned t = 0; t < live && ok; t++) ok = fwrite(bufs[t].data(), 1, bufs[t].size(), fp) == bufs[t].size();
     }
-    if (!ok.load()) {
+    if (!ok) {
         fclose(fp);
         return fail(F2V_EIO, "f2v_write_embd: short write to %s", path);
     }
