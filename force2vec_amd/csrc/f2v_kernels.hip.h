@@ -864,7 +864,7 @@ __device__ __forceinline__ void qprocess(const StepArgs &a, const HandSrc &hs, c
 // then costs one memory latency (the rows) instead of three dependent ones (item, ids, rows).
 // `between` runs once per call, when the list's first gathers are out and before anything is waited for (all threads of the
 // workgroup reach it: it may hold a barrier; -> true: the workgroup gives up).
-template <int OPT, int LPI, int NB, int U, bool FULL, class Between>
+template <int OPT, int LPI, int NB, int U, bool FULL, bool SKIP, class Between>
 __device__ __forceinline__ void qprocess_pre(const StepArgs &a, const HandSrc &hs, const uint32_t *ids, uint32_t cnt, uint32_t maxcnt, uint32_t t, uint32_t D,
                                              const float (&xi)[NB][4], float (&Y)[NB][4], double c0, const float *table, bool &bad,
                                              uint32_t (&j)[U], const uint32_t *next_ids, uint32_t next_cnt, Between &&between,
@@ -905,11 +905,17 @@ __device__ __forceinline__ void qprocess_pre(const StepArgs &a, const HandSrc &h
             if (last) j[u] = ((uint32_t)u < next_cnt) ? next_ids[u] : 0u;
             else j[u] = (g + U + u < cnt) ? ids[g + U + u] : 0u;
         }
-        // (wave-uniform: most groups of most wavefronts hold no handed row at all -- one scalar branch instead of a dozen)
-        bool anyh_lane = false;
+        // SKIP (the form for large graphs, where most groups of most wavefronts hold no handed row at all): one wave-uniform branch
+        // over the handed-row blocks instead of a dozen per-row ones -- batch 1024 / 2048 on RMAT-20 -1 ... -2 %.  Not in the forms for
+        // small graphs (a launch is one dependency chain, nearly every group holds handed rows): there the extra branch COST 4 % on
+        // cora at D = 16 (0.0676 -> 0.0702 s per 1200 epochs; profiles/r04_cora_regression_found.txt)
+        bool anyh = true;
+        if constexpr (SKIP) {
+            bool anyh_lane = false;
 #pragma unroll
-        for (int u = 0; u < U; ++u) anyh_lane = anyh_lane || handed[u];
-        const bool anyh = __builtin_amdgcn_ballot_w64(anyh_lane) != 0ull;
+            for (int u = 0; u < U; ++u) anyh_lane = anyh_lane || handed[u];
+            anyh = __builtin_amdgcn_ballot_w64(anyh_lane) != 0ull;
+        }
         // ... then, side by side again, every handed row whose flag was already up (most: they were written minibatches ago)
         if (anyh) {
 #pragma unroll
@@ -1707,7 +1713,7 @@ __global__ __launch_bounds__(256, (NB <= 2 && U <= 4) ? (MODE == 2 ? 2 : OPT == 
             }
             return false;
         };
-        qprocess_pre<OPT, LPI, NB, U, FULL>(a, hs, a.nbr_ids + it.nb, cnt, wave_max_of_items<LPI>(cnt), t, D, xi, Y, c0, table, bad, jpre,
+        qprocess_pre<OPT, LPI, NB, U, FULL, MODE == 0>(a, hs, a.nbr_ids + it.nb, cnt, wave_max_of_items<LPI>(cnt), t, D, xi, Y, c0, table, bad, jpre,
                                             a.nbr_ids + itn.nb, (itn.flags & kItemIdle) ? 0u : itn.cnt, between, prev_flags);
         if constexpr (!EARLY) (void)stage_late();
         if (quit) return;
