@@ -218,6 +218,37 @@ def test_embedding_readers_round_trip(tmp_path):
     assert F.read_embd(txt).shape == (3, 700) and np.abs(F.read_embd(txt) - wide).max() < 5e-6
 
 
+def test_fast_g_formatter_equals_printf(tmp_path):
+    """f2v_write_embd formats without printf where it can prove the digits (1e-4 <= |v| < 1e6: the scaled value is an exact double) and through
+    sprintf elsewhere: the text must be what "%g " gives for EVERY float -- here the edge cases (exact ties, carries into the next power of ten
+    and into 1e+06, the 1e-4 boundary from both sides, denormals, zeros, inf, nan) and 400 000 random bit patterns, against Python's own
+    "%g" (C semantics), in one- and many-threaded runs.  (All 2^32 patterns: tools/src/fmt_check.cpp.)"""
+    rng = np.random.default_rng(7)
+    edge = np.array([0.0, -0.0, 1.0, -1.0, 0.5, 0.25, 0.125, 1e-4, 9.9999997e-05, 1.00000005e-04, 9.99999e-05, 0.00010000005, 999999.5, 999999.44, 999999.4375,
+                     999999.9, 1e6, 1e-5, 123456.5, 123457.5, 0.1234565, 1.5, 2.5, 100000.5, 100001.5, 9.9999995, 99999.95, 0.999999523, 0.99999994,
+                     3.4028235e38, 1.17549435e-38, 1e-45, np.inf, -np.inf, np.nan, 65504.0, 0.333333343, 2.0 / 3.0, 1234567.0, 0.000123456789], dtype=np.float32)
+    ties = (np.arange(100000, 100064, dtype=np.float64) + 0.5).astype(np.float32) / np.float32(8.0)   # .0625 steps: exact ties at the 6th digit
+    bits = rng.integers(0, 1 << 32, 400000, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    vals = np.concatenate([edge, ties, bits, rng.uniform(-3, 3, 100000).astype(np.float32)])
+    vals[np.isnan(vals)] = np.float32(np.nan)  # (glibc prints a NaN's sign, Python's "%g" does not: both go through sprintf anyway)
+    dim = 8
+    vals = vals[: len(vals) // dim * dim].reshape(-1, dim)
+    want_lines = ["%d %d" % vals.shape] + ["%d " % (i + 1) + "".join("%g " % float(v) for v in row) for i, row in enumerate(vals)]
+    want = ("\n".join(want_lines) + "\n").encode()
+    for threads in ("1", "5"):
+        os.environ["F2V_IO_THREADS"] = threads
+        try:
+            path = str(tmp_path / ("g%s.embd" % threads))
+            F.write_embd(path, vals)
+            got = open(path, "rb").read()
+        finally:
+            del os.environ["F2V_IO_THREADS"]
+        if got != want:
+            gl, wl = got.split(b"\n"), want.split(b"\n")
+            k = next(i for i in range(min(len(gl), len(wl))) if gl[i] != wl[i])
+            raise AssertionError("line %d differs:\n got  %r\n want %r" % (k, gl[k][:200], wl[k][:200]))
+
+
 def test_header_is_plain_c_and_links(tmp_path):
     """include/f2v.h is a C header (no C++ or torch types in the signatures) and a C program links against libf2v."""
     src = tmp_path / "t.c"
