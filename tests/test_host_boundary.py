@@ -218,6 +218,57 @@ def test_embedding_readers_round_trip(tmp_path):
     assert F.read_embd(txt).shape == (3, 700) and np.abs(F.read_embd(txt) - wide).max() < 5e-6
 
 
+def test_threaded_embd_reader_equals_single_thread(tmp_path):
+    """f2v_read_embd splits a file above 4 MB over the host's threads at white space (ranges may start inside a row): the matrix is the
+    single-threaded one bit for bit, for any thread count, with rows shuffled, with tokens wrapped over lines, and with the special values
+    "%g" prints; one bad token anywhere (a value, an id, a repeated id) is refused and the FIRST bad row is the one named."""
+    rng = np.random.default_rng(11)
+    n, dim = 9000, 64
+    X = rng.uniform(-3, 3, (n, dim)).astype(np.float32)
+    X[5, 3], X[17, 0], X[8000, 63], X[44, 1] = np.inf, -np.inf, np.float32(1e-42), np.float32(3.3e38)
+    path = str(tmp_path / "big.embd")
+    F.write_embd(path, X)
+    assert os.path.getsize(path) > (4 << 20)
+    lines = open(path).read().splitlines()
+    order = rng.permutation(n)
+    body = [lines[1 + i] for i in order]
+    body[100] = body[100].replace(" ", "\n", 7)         # tokens are white-space separated, line ends included (what fscanf read)
+    body[101] = body[101].replace(" ", "\t  ", 3)
+    text = "\n".join([lines[0]] + body) + "\n"
+    open(path, "w").write(text)
+
+    def read(threads):
+        os.environ["F2V_IO_THREADS"] = str(threads)
+        try:
+            return F.read_embd(path)
+        finally:
+            del os.environ["F2V_IO_THREADS"]
+
+    one = read(1)
+    grid = np.array(text.split()[2:], dtype=np.float64).reshape(n, dim + 1)           # numpy's own parse of the same tokens
+    want = np.empty((n, dim), np.float32)
+    want[grid[:, 0].astype(np.int64) - 1] = grid[:, 1:].astype(np.float32)
+    assert np.array_equal(one, want) and np.isinf(one[5, 3]) and one[17, 0] == -np.inf
+    assert np.allclose(one[np.isfinite(X)], X[np.isfinite(X)], rtol=1e-5, atol=1e-44)
+    for threads in (2, 3, 7, 16):
+        assert np.array_equal(read(threads), one, equal_nan=True), threads
+    toks = text.split(" ")
+    for what, k, repl in (("value", len(toks) // 2, "1.5x"), ("value", len(toks) - 40, "abc"), ("id", None, None)):
+        bad = list(toks)
+        if what == "value":
+            bad[k] = repl
+            open(path, "w").write(" ".join(bad))
+        else:
+            rows = [lines[0]] + list(body)
+            rows[6001] = "%d %s" % (order[10] + 1, rows[6001].split(" ", 1)[1])   # row 6001 repeats an earlier id
+            open(path, "w").write("\n".join(rows) + "\n")
+        for threads in (1, 5):
+            with pytest.raises(F.F2VError) as e:
+                read(threads)
+            if what == "id":
+                assert "row 6001 of 9000" in str(e.value) or "row 11 of 9000" in str(e.value), str(e.value)
+
+
 def test_fast_g_formatter_equals_printf(tmp_path):
     """f2v_write_embd formats without printf where it can prove the digits (1e-4 <= |v| < 1e6: the scaled value is an exact double) and through
     sprintf elsewhere: the text must be what "%g " gives for EVERY float -- here the edge cases (exact ties, carries into the next power of ten
