@@ -100,7 +100,8 @@ struct PushExport {
     uint32_t magic, n, D, cur;
     uint32_t landing, landing_cap;
     char bus_id[16];  // PCI bus id of the exporting rank's GPU: ranks that share a card run without "piece_affinity"
-    char reserved[F2V_PUSH_EXPORT_BYTES - 3 * sizeof(hipIpcMemHandle_t) - 24 - 16];
+    uint32_t caps;    // bit 0: this rank's GPU starts workgroups XCD-round-robin in index order (what chained launches count on)
+    char reserved[F2V_PUSH_EXPORT_BYTES - 3 * sizeof(hipIpcMemHandle_t) - 28 - 16];
 };
 static_assert(sizeof(PushExport) == F2V_PUSH_EXPORT_BYTES, "export blob layout");
 static_assert(kMaxRanks == F2V_PUSH_MAX_RANKS, "rank limit");
@@ -188,6 +189,13 @@ struct f2v_ctx {
     // launch, what is left of the form is "a split row's pieces meet in LDS" (no partial sums through HBM, no tree nodes below
     // fanin^2 pieces): the plain launch form's alternative for large minibatches, measured and rejected (profiles/r04_*)
     bool wide_single = false;
+    // "replicate_small": f2v_train_sharded at a batch size f2v_train would run chained (the reference's default 384 is one) runs the WHOLE
+    // epoch on every rank and exchanges nothing: such an epoch is one chain of row-to-row dependencies (1 432 hops of ~5 us at batch 256
+    // on RMAT-20) that a hop over xGMI can only lengthen -- sharded with one launch and one barrier per minibatch it took 41 ms per epoch
+    // at batch 384 on two ranks where one GPU takes 6.7.  Every rank holds the same matrix and the same rand() state before and after
+    // (the chained forms are deterministic).  1 (default): where no peer shares this rank's GPU (waiting workgroups of two processes on
+    // one card can starve each other: bounded and recovered, but slow); 2: always; 0: never.
+    int replicate_small = 1;
     int wide_samples_early = -1;  // "wide_samples_early": StepArgs::samples_early; -1 = automatic (graphs of up to 2 M nonzeros: the launch is one dependency chain)
     uint32_t wide_rounds = 0;   // rounds per phase of such a workgroup (0: one for minibatches of up to 512 rows, else as many as fill the piece slots)
     uint32_t wide_span = 2;     // fan-in groups per helper workgroup
@@ -211,6 +219,7 @@ struct f2v_ctx {
     int rows_in_flight = 0;  // 0: the kernels' default (4 at D = 128 and 256, 8 below)
     bool class_cut = true;         // split rows are also cut where their neighbour ids cross into the next eighth of the id range (piece_cuts)
     bool piece_affinity = true;    // hub pieces are placed on the XCD that owns their neighbours' id range (see plan_for)
+    bool last_replicated = false;  // the last f2v_train_sharded ran the whole epoch on this rank ("replicate_small")
     bool shared_card = false;      // a peer of the push exchange runs on the same GPU: placement goes back to same-XCD groups
     bool count_compulsory = false;  // plans also count their compulsory bytes (f2v_stats.compulsory_bytes; costs O(nnz) per new plan)
     SeenScratch seen_scratch;  // ... with this marker array
@@ -232,6 +241,7 @@ struct f2v_ctx {
         uint32_t *d_masks = nullptr, *d_patch = nullptr;
         size_t patch_cap = 0;
         uint64_t pushed_per_epoch = 0, rows_pushed = 0, rows_allgather = 0;
+        bool any_shared = false, all_chain = true;  // over all attached ranks (f2v_push_attach): "replicate_small"
         // Landing-buffer mode: hipIpcOpenMemHandle never returns for an allocation of 2 GiB or more (ROCm 7.x), so a
         // matrix that large cannot be mapped into the peers.  The peers then push a minibatch's rows into a small
         // mapped buffer (two halves, alternating per exchange) and unpack_rows_kernel moves them into the matrix
@@ -2183,6 +2193,11 @@ int f2v_set_param(f2v_handle c, const char *name, int64_t value) {
         c->wide_single = value != 0;
         return F2V_OK;
     }
+    if (!strcmp(name, "replicate_small")) {
+        if (value < 0 || value > 2) return fail(F2V_EINVAL, "replicate_small must be 0 (never), 1 (where no peer shares the GPU) or 2 (always)");
+        c->replicate_small = (int)value;
+        return F2V_OK;
+    }
     if (!strcmp(name, "wide_samples_early")) {
         if (value < -1 || value > 1) return fail(F2V_EINVAL, "wide_samples_early must be -1 (automatic), 0 or 1");
         c->wide_samples_early = (int)value;
@@ -2314,6 +2329,8 @@ int f2v_get_param(f2v_handle c, const char *name, int64_t *out) {
     if (!strcmp(name, "wide_max_batch")) { *out = c->wide_max_batch; return F2V_OK; }
     if (!strcmp(name, "wide_min_width")) { *out = c->wide_min_width; return F2V_OK; }
     if (!strcmp(name, "wide_single")) { *out = c->wide_single ? 1 : 0; return F2V_OK; }
+    if (!strcmp(name, "replicate_small")) { *out = c->replicate_small; return F2V_OK; }
+    if (!strcmp(name, "last_train_replicated")) { *out = c->last_replicated ? 1 : 0; return F2V_OK; }
     if (!strcmp(name, "plan_resident_bytes")) {  // launch plans resident on the host (and, uploaded, in HBM): items, jobs, workgroup descriptors, tree nodes
         *out = (int64_t)(c->h_items.size() * sizeof(Item) + c->h_jobs.size() * sizeof(WJob) + c->h_wide.size() * sizeof(WideDesc) + c->h_wg.size() * sizeof(WgDesc) + c->h_hubs.size() * sizeof(FinItem));
         return F2V_OK;
@@ -2617,6 +2634,23 @@ int f2v_train_sharded(f2v_handle c, int option, uint32_t iters, uint32_t batch, 
                       double *seconds_out) {
     if (!c) return fail(F2V_EINVAL, "null handle");
     if (!c->push.attached) return fail(F2V_ESTATE, "f2v_train_sharded: f2v_push_attach first");
+    const int math = math_of_option(option);
+    c->last_replicated = false;
+    if (math && batch && iters && !(math == 7 && bs_mode) && c->have_x && c->push.all_chain &&
+        (c->replicate_small == 2 || (c->replicate_small == 1 && !c->push.any_shared))) {
+        // Every rank must decide alike: the graph, the batch, the engine parameters (the callers set them alike on every rank, as they
+        // must for the sharded form) and what f2v_push_attach learnt about ALL ranks.  Not this rank's "merge_finalize": a rank whose
+        // in-grid waits are suspended after a recovered give-up still runs the whole epoch itself, one launch per minibatch -- same bits.
+        const bool waits = c->merge_fin;
+        c->merge_fin = true;
+        const bool replicate = chain_usable(c, math, batch, bs_mode, false);
+        c->merge_fin = waits;
+        if (replicate) {
+            c->push.rows_pushed = c->push.rows_allgather = 0;
+            c->last_replicated = true;
+            return f2v_train(c, option, iters, batch, ns, lr, bs_mode, seconds_out);
+        }
+    }
     return train_impl(c, option, iters, batch, ns, lr, bs_mode, seconds_out, true);
 }
 
@@ -3057,6 +3091,7 @@ int f2v_push_export(f2v_handle c, void *handles_out) {
         char bus[64] = {};
         if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, c->device) == hipSuccess) strncpy(e.bus_id, bus, sizeof e.bus_id - 1);
     }
+    e.caps = c->xcc_round_robin ? 1u : 0u;
     memcpy(handles_out, &e, sizeof e);
     c->push.exported = true;
     return F2V_OK;
@@ -3091,6 +3126,19 @@ int f2v_push_attach(f2v_handle c, uint32_t rank, uint32_t world, const void *all
         if (shared != c->shared_card) {  // placement of the hub pieces depends on it
             c->shared_card = shared;
             drop_plans(c);
+        }
+        // what every rank must decide alike ("replicate_small"): do any two ranks share a card, can every rank chain
+        c->push.any_shared = false;
+        c->push.all_chain = true;
+        for (uint32_t r = 0; r < world; r++) {
+            PushExport e;
+            memcpy(&e, all + r, sizeof e);
+            if (!(e.caps & 1u)) c->push.all_chain = false;
+            for (uint32_t q = r + 1; q < world; q++) {
+                PushExport f;
+                memcpy(&f, all + q, sizeof f);
+                if (e.bus_id[0] == 0 || !memcmp(e.bus_id, f.bus_id, sizeof e.bus_id)) c->push.any_shared = true;
+            }
         }
     }
     c->push.rank = rank;

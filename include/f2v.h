@@ -103,7 +103,12 @@ F2V_API int f2v_get_embeddings(f2v_handle h, float *x_out);
  * dropped and rebuilt on demand beyond that (a run that alternates many batch sizes).  "wide_single" = 1 (measurement only) lets the wide form run
  * launches of one minibatch.
  * Sharded runs: "push_fused" (default 1: the step kernels push their rows themselves, 0: a kernel behind
- * them does), "push_timeout_ms".
+ * them does), "push_timeout_ms"; "replicate_small" (default 1): f2v_train_sharded at a batch size that f2v_train runs chained (up to
+ * "chain_max_batch" rows: the reference's default 384 is one) runs the whole call on EVERY rank and exchanges nothing -- such an epoch is one
+ * row-to-row dependency chain that hops over xGMI can only lengthen (sharded: 41 ms per epoch at batch 384 on two ranks; one GPU: 6.7 ms) --
+ * where no two attached ranks share a GPU and every rank's GPU can chain (both learnt by f2v_push_attach, so every rank decides alike);
+ * 2: also on a shared GPU; 0: never.  Bits, rand() state and the matrix every rank holds afterwards are f2v_train's.
+ * f2v_get_param("last_train_replicated") tells.
  * "fast_rng" = 1 selects the NON-PARITY fast mode: initial embeddings and the option-7
  * walks are generated on the device by a counter-based RNG (same distributions, different numbers than
  * the reference's libc rand() stream); negative-sample ids still come from the handle's rand() stream.

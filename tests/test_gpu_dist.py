@@ -43,6 +43,9 @@ def _gloo_worker(rank, world, port, case, outdir, exchange="allgather"):
     eng = F.Engine(rp, ci, dim, device=0)
     eng.srand(1)
     eng.init_embeddings(0 if option in (5, 8, 11) else 1)
+    replicated = exchange == "push_replicated"
+    if replicated:
+        exchange = "push"
     if exchange in ("push", "push_unfused", "push_landing", "push_landing_unfused"):
         # the engine's own exchange: peers' matrices mapped through HIP IPC (here: other processes on the same GPU),
         # rows pushed by a HIP kernel, device-side flag barrier; gloo only carries the handles
@@ -53,6 +56,9 @@ def _gloo_worker(rank, world, port, case, outdir, exchange="allgather"):
         if exchange.endswith("unfused"):  # rows pushed by a kernel of their own behind the step instead of by the step itself
             eng.set_param("push_fused", 0)
         exchange = "push"
+        if replicated:  # (1, the default, replicates only where no two ranks share a card: here they all do)
+            assert eng.get_param("replicate_small") == 1
+            eng.set_param("replicate_small", 2)
     elif exchange == "allgather":
         comm = fdist.HostStageComm(dist, rank, world)
     elif exchange == "need":
@@ -72,7 +78,15 @@ def _gloo_worker(rank, world, port, case, outdir, exchange="allgather"):
         comm = fdist.NeedExchange(dist, rank, world, device=0, backend="device")
     tr = fdist.ShardedTrainer(eng, rank, world, comm)
     tr.train(option, iters, batch, 5, 0.02, bs)
-    if exchange == "push":
+    if replicated:
+        # a minibatch small enough to chain: every rank ran the whole epochs itself, in the chained form, and pushed nothing ...
+        assert eng.get_param("last_train_replicated") == 1 and eng.get_param("last_train_form") in (1, 2)
+        assert eng.push_stats() == {"rows_pushed": 0, "rows_allgather": 0}
+        # ... and the same attachment shards the next call (one minibatch per epoch cannot chain): the ranks still hold the same matrix
+        tr.train(option, 1, eng.n, 5, 0.02, bs)
+        st = eng.push_stats()
+        assert eng.get_param("last_train_replicated") == 0 and 0 < st["rows_pushed"] <= st["rows_allgather"]
+    elif exchange == "push":
         # a second run on the same attachment continues where the first stopped, exactly like two f2v_train calls
         tr.train(option, 1, batch, 5, 0.02, bs)
         st = eng.push_stats()
@@ -113,6 +127,34 @@ def test_push_exchange_between_processes_sharing_the_gpu(case, world, tmp_path):
         pytest.skip("covered by world 2")
     mp.spawn(_gloo_worker, args=(world, _free_port(), case, str(tmp_path), "push"), nprocs=world, join=True)
     want = _single_twice(case)
+    for r in range(world):
+        assert np.array_equal(np.load(str(tmp_path / ("r%d.npy" % r))), want)
+
+
+def _single_then_whole(case):
+    import force2vec_amd as F
+    graph, option, iters, batch, dim, bs = case
+    rp, ci = F.read_mtx(golden_graph_path(graph))
+    eng = F.Engine(rp, ci, dim, device=0)
+    eng.srand(1)
+    eng.init_embeddings(0 if option in (5, 8, 11) else 1)
+    eng.train(option, iters, batch, 5, 0.02, bs)
+    eng.train(option, 1, eng.n, 5, 0.02, bs)
+    X = eng.get_embeddings()
+    eng.close()
+    return X
+
+
+@pytest.mark.parametrize("case", [("cora.mtx", 5, 40, 256, 128, 0), ("cora.mtx", 6, 3, 300, 64, 0), ("karate.mtx", 7, 3, 16, 64, 0)])
+def test_sharded_call_at_a_chainable_batch_runs_replicated(case, tmp_path):
+    """f2v_train_sharded at a batch size that chains ("replicate_small"): an epoch of small minibatches is one row-to-row dependency chain,
+    which hops over xGMI can only lengthen, so every rank runs the whole call itself in the chained form and nothing is exchanged; the
+    ranks end with the same matrix -- f2v_train's, bit for bit -- and the same rand() state, and the next, sharded call of the same
+    attachment (whose pushes land in matrices that must therefore already agree) continues from it."""
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_gloo_worker, args=(world, _free_port(), case, str(tmp_path), "push_replicated"), nprocs=world, join=True)
+    want = _single_then_whole(case)
     for r in range(world):
         assert np.array_equal(np.load(str(tmp_path / ("r%d.npy" % r))), want)
 
