@@ -261,6 +261,7 @@ def live_traffic(args, kname, budget_s):
                    "launches_sampled": out.get("launches_fetch"), "seconds": time.time() - t_start}
             if out.get("TCC_MISS_sum"):
                 res["l2_hit_rate"] = out["TCC_HIT_sum"] / (out["TCC_HIT_sum"] + out["TCC_MISS_sum"])
+                res["l2_request_bytes"] = (out["TCC_HIT_sum"] + out["TCC_MISS_sum"]) * 128.0  # 128-byte requests, hits and misses
             if "note" in out:
                 res["note"] = out["note"]
             return res
@@ -717,6 +718,11 @@ def main():
                 roof["l2_miss_GBs"] = live["traffic"] / t_launch * 1e-9
                 if "l2_hit_rate" in live:
                     roof["l2_hit_rate"] = live["l2_hit_rate"]
+                if "l2_request_bytes" in live:
+                    # what the L2s SERVED (hits and misses, TCC_HIT + TCC_MISS requests of 128 B); row_gather_from_l2_GBs_on_this_box below is the
+                    # rate at which they deliver row gathers that all hit (profiles/r04_launch_time_decomposition.txt)
+                    roof["l2_request_bytes_per_launch"] = live["l2_request_bytes"]
+                    roof["l2_request_GBs"] = live["l2_request_bytes"] / t_launch * 1e-9
                 roof["traffic_over_compulsory"] = live["traffic"] / comp
                 roof["hbm_bytes_per_launch_between"] = [comp, live["traffic"]]
                 if "note" in live:
@@ -753,6 +759,14 @@ def main():
                 roof["row_gather_from_hbm_GBs_on_this_box"] = g.value  # random 512-B rows of a 4-GiB table, each once
             if L.f2v_diag_gather_rate(local_rank, 64 << 20, 2, ctypes.byref(g)) == 0:
                 roof["row_gather_from_infinity_cache_GBs_on_this_box"] = g.value  # the same from a 64-MiB table
+            if L.f2v_diag_gather_rate(local_rank, 1 << 20, 2, ctypes.byref(g)) == 0:
+                roof["row_gather_from_l2_GBs_on_this_box"] = g.value  # the same from a 1-MiB table: every XCD's L2 holds it -- the L2s' delivery rate for row gathers
+                if roof.get("l2_request_GBs"):
+                    roof["l2_request_frac_of_l2_gather_rate"] = roof["l2_request_GBs"] / g.value
+                    roof["launch_time_note"] = ("the launch's L2 requests (hits + misses) move at %.2f of the rate at which this box's L2s deliver row gathers that all hit, its misses at %.2f "
+                                                "of the box's pure-miss gather rate from the Infinity Cache: neither path is saturated; a gather-only replay of the same launch plans "
+                                                "takes 0.88 of the kernel's time, 0.71 with the hub chunk cut to 32 (no long dependent chains) -- profiles/r04_launch_time_decomposition.txt"
+                                                % (roof["l2_request_GBs"] / g.value, roof.get("l2_miss_GBs", 0.0) / max(roof.get("row_gather_from_infinity_cache_GBs_on_this_box", 0.0), 1e-9)))
         res["roofline"] = roof
     extra = {}
     if rank == 0 and not use_dist:

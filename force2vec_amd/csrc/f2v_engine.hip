@@ -3509,6 +3509,41 @@ int f2v_test_gather_calibration(int device, uint32_t rows, uint32_t reps) {
     return F2V_OK;
 }
 
+// The memory side of one real launch, alone: the plan of minibatch [row_lo, row_hi) (options 5/6 at D = 128: the headline's layout) replayed by
+// plan_gather_kernel -- `reps` launches, the best time in microseconds.  The second matrix is written where mode bit 1 is set: the
+// handle's embeddings are garbage afterwards.
+int f2v_test_plan_gather(f2v_handle c, uint32_t row_lo, uint32_t row_hi, uint32_t mode, uint32_t reps, double *us_out) {
+    if (!c || !us_out || row_lo >= row_hi || row_hi > c->n || reps == 0) return fail(F2V_EINVAL, "f2v_test_plan_gather: bad argument");
+    if (subwave_width(c) != 128 || c->D != 128) return fail(F2V_EINVAL, "f2v_test_plan_gather: D = 128 only");
+    HIPC(hipSetDevice(c->device));
+    int rc = flush_pending(c);
+    if (rc != F2V_OK) return rc;
+    const Plan plan = plan_for(c, row_lo, row_hi, false);
+    if ((rc = upload_plans(c)) != F2V_OK) return rc;
+    float *d_o = nullptr;
+    HIPC(hipMalloc((void **)&d_o, 64));
+    hipEvent_t e0, e1;
+    HIPC(hipEventCreate(&e0));
+    HIPC(hipEventCreate(&e1));
+    const uint32_t G = 1u << ((mode >> 2) & 3u);  // mode bits 2-3: a wavefront takes 1 / 2 / 4 / 8 consecutive groups of items
+    const uint32_t blocks = ((plan.n_items + 16u * 8u * G - 1u) / (16u * 8u * G)) * 8u;  // (plan_gather_kernel: workgroup B takes the plan's workgroups B % 8 + 8 (G (B / 8) + k))
+    float best = 1e30f;
+    for (uint32_t r = 0; r < reps + 2; r++) {
+        HIPC(hipEventRecord(e0, c->stream));
+#define F2V_PG(GG) hipLaunchKernelGGL((plan_gather_kernel<16, 2, 4, GG>), dim3(blocks), dim3(256), 0, c->stream, c->d_X[c->cur], c->d_X[c->cur ^ 1], c->d_items + plan.item_off, plan.n_items, c->d_colids, mode & 3u, d_o)
+        if (G == 1) F2V_PG(1); else if (G == 2) F2V_PG(2); else if (G == 4) F2V_PG(4); else F2V_PG(8);
+#undef F2V_PG
+        HIPC(hipEventRecord(e1, c->stream));
+        HIPC(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIPC(hipEventElapsedTime(&ms, e0, e1));
+        if (r >= 2 && ms < best) best = ms;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d_o);
+    *us_out = best * 1e3;
+    return F2V_OK;
+}
+
 #endif  // F2V_TEST_HOOKS
 
 // Stand-alone rehearsal of what f2v_push_attach + the push kernels need from the machine, meant to run in a

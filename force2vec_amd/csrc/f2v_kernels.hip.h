@@ -2026,6 +2026,74 @@ struct PreflightArgs {
     uint64_t last_word;  // index of the last 32-bit word of the data buffers (the far end of the mapping is exercised too)
 };
 
+#ifdef F2V_TEST_HOOKS
+// Self-test build only (f2v_test_plan_gather): the MEMORY side of a real launch and nothing else -- the plan's items in the plan's order, their
+// neighbour rows gathered with the step kernel's pattern (lane groups in lockstep up to the longest item of the wavefront, U rows in
+// flight), no interaction computed, no samples.  mode bit 0: the item's own row is read as well; bit 1: whole-row items store a row.
+template <int LPI, int NB, int U, int G>
+__global__ __launch_bounds__(256, 5) void plan_gather_kernel(const float *X, float *Xn, const Item *items, uint32_t n_items, const uint32_t *nbr_ids, uint32_t mode, float *out) {
+    // G > 1 (experiment): a wavefront takes G consecutive groups of items, one after the other; all their items are requested at once and
+    // the first ids of group k + 1 while group k's rows are gathered -- the start-up chain item -> ids -> rows is paid once per wavefront
+    constexpr uint32_t D = 4u * LPI * NB, IPW = 64u / LPI;
+    const uint32_t lane = threadIdx.x & 63u, t = lane & (LPI - 1u), q = lane / LPI;
+    // (the plan's workgroups go to the XCDs round robin and hub pieces sit in the workgroups of "their" XCD: workgroup B of this grid takes
+    // the plan's workgroups B % 8 + 8 (G (B / 8) + k), k < G -- the same XCD)
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wpb = blockDim.x >> 6;
+    auto group_of = [&](int k) { return ((blockIdx.x & 7u) + 8u * (G * (blockIdx.x >> 3) + (uint32_t)k)) * wpb + wv; };
+    if (IPW * group_of(0) >= n_items) return;
+    Item it[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+        const uint32_t idx = IPW * group_of(k) + q;
+        if (idx < n_items) it[k] = items[idx];
+        else { it[k].row = 0; it[k].nb = 0; it[k].cnt = 0; it[k].flags = 0; }
+    }
+    uint32_t j[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) j[u] = ((uint32_t)u < it[0].cnt) ? nbr_ids[it[0].nb + u] : 0u;
+    float keep = 0.f;
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+        const uint32_t idx = IPW * group_of(k) + q;
+        float4 acc[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[b] = (mode & 1u) ? *reinterpret_cast<const float4 *>(X + (size_t)it[k].row * D + t * 4 + 4 * LPI * b) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const uint32_t *ids = nbr_ids + it[k].nb;
+        const uint32_t cnt = it[k].cnt, maxcnt = wave_max_of_items<LPI>(cnt);
+        uint32_t g = 0;
+        do {
+            float4 xj[U][NB];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (g + u < cnt) {
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) xj[u][b] = *reinterpret_cast<const float4 *>(X + (size_t)j[u] * D + t * 4 + 4 * LPI * b);
+                }
+            const bool last = g + U >= maxcnt;  // (uniform)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (last) j[u] = (k + 1 < G && (uint32_t)u < it[k + 1 < G ? k + 1 : k].cnt) ? nbr_ids[it[k + 1 < G ? k + 1 : k].nb + u] : 0u;
+                else j[u] = (g + U + u < cnt) ? ids[g + U + u] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (g + u < cnt) {
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) { acc[b].x += xj[u][b].x; acc[b].y += xj[u][b].y; acc[b].z += xj[u][b].z; acc[b].w += xj[u][b].w; }
+                }
+            g += U;
+        } while (g < maxcnt);
+        if ((mode & 2u) && idx < n_items && !(it[k].flags & kItemPartial)) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) *reinterpret_cast<float4 *>(Xn + (size_t)it[k].row * D + t * 4 + 4 * LPI * b) = acc[b];
+        } else {
+            keep += acc[0].x + acc[NB - 1].y;
+        }
+    }
+    if (keep == 12345.678f) out[0] = keep;
+}
+#endif
+
 __global__ void preflight_write_kernel(const PreflightArgs a) {
     const uint32_t q = threadIdx.x;
     if (q >= a.world) return;

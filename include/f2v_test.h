@@ -50,6 +50,12 @@ F2V_API int f2v_test_stamps(f2v_handle h, int on, unsigned long long *out);
 F2V_API int f2v_test_wide_plan_check(const uint32_t *rowptr, const uint32_t *colids, uint32_t n, uint64_t nnz, uint32_t dim, uint32_t batch, int walk,
                              const char *const *names, const int64_t *values, uint32_t n_params, uint64_t *stats_out);
 
+/* The memory side of one real launch, alone (D = 128): the launch plan of minibatch [row_lo, row_hi) replayed by a kernel that only gathers --
+ * the plan's items in the plan's order, lane groups in lockstep, 4 rows in flight, nothing computed, no negative samples, no combine trees;
+ * mode bit 0: every item also reads its own row, bit 1: every whole-row item stores a row into the second matrix (the embeddings are garbage
+ * afterwards).  Best of `reps` launches in microseconds.  tools/plan_gather_probe.py. */
+F2V_API int f2v_test_plan_gather(f2v_handle h, uint32_t row_lo, uint32_t row_hi, uint32_t mode, uint32_t reps, double *us_out);
+
 #ifdef __cplusplus
 }
 #endif
