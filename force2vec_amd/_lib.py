@@ -92,6 +92,7 @@ TEST_SIGNATURES = {
     "f2v_test_chain_nowait": (C.c_int, [C.c_void_p, C.c_int]),
     "f2v_test_withhold_row": (C.c_int, [C.c_void_p, C.c_uint32]),
     "f2v_test_stamps": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]),
+    "f2v_test_xcd_times": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]),
     "f2v_test_plan_gather": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
     "f2v_test_wide_plan_check": (C.c_int, [u32p, u32p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.c_uint32, C.POINTER(C.c_uint64)]),
 }

@@ -147,6 +147,7 @@ struct f2v_ctx {
     uint32_t test_withhold_slot = kNoSlot, test_withhold_row = kNoSlot;
     uint32_t test_chain_mode = 0;  // f2v_test_chain_nowait's argument as given (bit 0 = the old on/off)
     bool test_chain_nowait = false;  // timing experiment: chained launches without their row waits (results are then wrong)
+    unsigned long long *d_xcd = nullptr;     // f2v_test_xcd_times (StepArgs::xcd_times)
     unsigned long long *d_stamps = nullptr;  // f2v_test_stamps: 4 wall-clock words per row (StepArgs::stamps)
 #endif
     bool merge_fin = true, capturing = false;  // all combine-tree levels in one launch (not while a hipGraph is captured)
@@ -1342,6 +1343,9 @@ int launch_step(f2v_ctx *c, int math, uint32_t batch_lo, uint32_t batch_hi, uint
     a.bs_mode = bs_mode ? 1u : 0u;
     a.unit_degi = c->unit_degi ? 1u : 0u;
     a.lr = lr;
+#ifdef F2V_TEST_HOOKS
+    a.xcd_times = c->d_xcd;
+#endif
     push = push && c->push.attached && c->push.world > 1;
     if (push) fill_targets(c, a.push, c->cur ^ 1, batch_lo, push_masks);
 
@@ -1964,6 +1968,7 @@ int f2v_destroy(f2v_handle c) {
         if (p) (void)hipFree(p);
 #ifdef F2V_TEST_HOOKS
     if (c->d_stamps) (void)hipFree(c->d_stamps);
+    if (c->d_xcd) (void)hipFree(c->d_xcd);
 #endif
     if (c->h_kerr) (void)hipHostFree(c->h_kerr);
     for (hipEvent_t e : c->ev_snap)
@@ -3506,6 +3511,25 @@ int f2v_test_gather_calibration(int device, uint32_t rows, uint32_t reps) {
     HIPC(hipGetLastError());
     HIPC(hipDeviceSynchronize());
     (void)hipFree(d_t); (void)hipFree(d_i); (void)hipFree(d_o);
+    return F2V_OK;
+}
+
+// Per-XCD timing of the launches that follow (one launch per minibatch): on = 1 allocates / clears the 32 words (StepArgs::xcd_times), `out`
+// (32 words, may be null) receives what has been recorded since; on = 0 frees them.
+int f2v_test_xcd_times(f2v_handle c, int on, unsigned long long *out) {
+    if (!c) return fail(F2V_EINVAL, "null handle");
+    HIPC(hipSetDevice(c->device));
+    HIPC(hipStreamSynchronize(c->stream));
+    if (out && c->d_xcd) HIPC(hipMemcpy(out, c->d_xcd, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (on) {
+        if (!c->d_xcd) HIPC(hipMalloc((void **)&c->d_xcd, 32 * sizeof(unsigned long long)));
+        unsigned long long init[32];
+        for (int k = 0; k < 32; k++) init[k] = (k >= 8 && k < 16) ? ~0ull : 0ull;
+        HIPC(hipMemcpy(c->d_xcd, init, sizeof init, hipMemcpyHostToDevice));
+    } else if (c->d_xcd) {
+        (void)hipFree(c->d_xcd);
+        c->d_xcd = nullptr;
+    }
     return F2V_OK;
 }
 

@@ -122,6 +122,9 @@ struct StepArgs {
     unsigned long long *stamps;
     uint32_t test_withhold_row;       // f2v_test_withhold_row: chained launches never store this row's flag (kNoSlot: none)
     uint32_t test_nowait;             // f2v_test_chain_nowait (wide form): no row of the launch is waited for
+    // f2v_test_xcd_times (one launch per minibatch): per XCD k -- [k] latest end of a workgroup, [8 + k] earliest start, [16 + k] sum of the
+    // workgroups' durations, [24 + k] workgroups (100-MHz wall clock); nullptr: off
+    unsigned long long *xcd_times;
 #endif
 };
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
@@ -1186,7 +1189,21 @@ __device__ __forceinline__ void qstep_body(const StepArgs &a, const uint32_t blk
 
 template <int OPT, int LPI, int NB, int U, bool PUSH = false, bool FULL = true>
 __global__ __launch_bounds__(256) void qstep_kernel(const StepArgs a) {
+#ifdef F2V_TEST_HOOKS
+    const unsigned long long t0 = a.xcd_times ? wall_clock64() : 0ull;
+#endif
     qstep_body<OPT, LPI, NB, U, PUSH, FULL, false>(a, blockIdx.x);
+#ifdef F2V_TEST_HOOKS
+    if (a.xcd_times && threadIdx.x == 0u) {
+        uint32_t id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(id));
+        const unsigned long long t1 = wall_clock64();
+        atomicMax(a.xcd_times + (id & 7u), t1);
+        atomicMin(a.xcd_times + 8u + (id & 7u), t0);
+        atomicAdd(a.xcd_times + 16u + (id & 7u), t1 - t0);
+        atomicAdd(a.xcd_times + 24u + (id & 7u), 1ull);
+    }
+#endif
 }
 
 // ---- chained minibatches: several consecutive minibatches in ONE launch ---------------------------------------------

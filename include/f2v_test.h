@@ -50,6 +50,11 @@ F2V_API int f2v_test_stamps(f2v_handle h, int on, unsigned long long *out);
 F2V_API int f2v_test_wide_plan_check(const uint32_t *rowptr, const uint32_t *colids, uint32_t n, uint64_t nnz, uint32_t dim, uint32_t batch, int walk,
                              const char *const *names, const int64_t *values, uint32_t n_params, uint64_t *stats_out);
 
+/* Per-XCD timing of the launches that follow (the sub-wave step kernel, one launch per minibatch): on = 1 clears 32 words -- per XCD k: [k] the latest end
+ * of a workgroup, [8 + k] the earliest start, [16 + k] the sum of its workgroups' durations, [24 + k] its workgroups (100-MHz device wall clock) --, `out`
+ * (may be null) receives what has been recorded since the last call; on = 0 frees them.  tools/xcd_balance_probe.py. */
+F2V_API int f2v_test_xcd_times(f2v_handle h, int on, unsigned long long *out);
+
 /* The memory side of one real launch, alone (D = 128): the launch plan of minibatch [row_lo, row_hi) replayed by a kernel that only gathers --
  * the plan's items in the plan's order, lane groups in lockstep, 4 rows in flight, nothing computed, no negative samples, no combine trees;
  * mode bit 0: every item also reads its own row, bit 1: every whole-row item stores a row into the second matrix (the embeddings are garbage
