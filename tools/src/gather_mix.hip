@@ -8,6 +8,9 @@
 #include <cstdint>
 #include <vector>
 #include <random>
+#include <algorithm>
+#include <cmath>
+#include <cstring>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 template <int U>
@@ -127,11 +130,47 @@ int main(int argc, char **argv) {
     const int variant = argc > 4 ? atoi(argv[4]) : 0;       // 0: the step kernel's pattern; 8: 8 rows in flight; 1: one row per wavefront instruction (16 in flight); 2: ids grid-strided; 3: 16 ids per load, shuffled
     const size_t lds_pad = argc > 5 ? strtoull(argv[5], nullptr, 10) : 0;  // dynamic LDS per workgroup: bounds the workgroups per CU (160 KiB / pad)
     printf("variant %d, %zu bytes of LDS padding per workgroup\n", variant, lds_pad);
+    if (getenv("GATHER_MIX_ZIPF")) {
+        // one table, rows drawn with power-law popularity (weight of the r-th most popular row: (r + 1)^-s, popular rows scattered over the table):
+        // hits and misses as a graph's neighbour stream produces them, not as two uniform populations
+        for (const char *tok = strtok(getenv("GATHER_MIX_ZIPF"), ","); tok; tok = strtok(nullptr, ",")) {
+            const double sexp = atof(tok);
+            std::vector<double> cdf(cold_rows);
+            double acc = 0;
+            for (uint32_t r = 0; r < cold_rows; r++) { acc += pow((double)r + 1.0, -sexp); cdf[r] = acc; }
+            std::vector<uint32_t> perm(cold_rows);
+            for (uint32_t r = 0; r < cold_rows; r++) perm[r] = r;
+            for (uint32_t r = cold_rows - 1; r > 0; r--) std::swap(perm[r], perm[mt() % (r + 1)]);
+            for (auto &v : ids) {
+                const double u = (double)(mt() >> 11) * (1.0 / 9007199254740992.0) * acc;
+                v = hot_rows + perm[(uint32_t)(std::lower_bound(cdf.begin(), cdf.end(), u) - cdf.begin())];
+            }
+            CK(hipMemcpy(d_i, ids.data(), n * 4, hipMemcpyHostToDevice));
+            float best = 1e30f;
+            for (int r = -400; r < 7; r++) {
+                if (r >= 0) CK(hipEventRecord(e0, 0));
+                hipLaunchKernelGGL((gather_kernel<4>), dim3(blocks), dim3(256), 0, 0, d_t, d_i, per_group, d_o);
+                if (r < 0) continue;
+                CK(hipEventRecord(e1, 0));
+                CK(hipEventSynchronize(e1));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                if (ms < best) best = ms;
+            }
+            std::vector<uint32_t> sorted(ids);
+            std::sort(sorted.begin(), sorted.end());
+            const size_t distinct = std::unique(sorted.begin(), sorted.end()) - sorted.begin();
+            printf("power law s = %.2f over %u rows: %zu distinct rows in %llu reads; %.1f us = %.2f TB/s of rows\n", sexp, cold_rows, distinct, (unsigned long long)n, best * 1e3,
+                   n * 512.0 / (best * 1e-3) * 1e-12);
+            fflush(stdout);
+        }
+        return 0;
+    }
     const double fr[] = {0.0, 1.0, 0.25, 0.5, 0.75, 0.9};
     for (double f : fr) {
         for (auto &v : ids) {
             const bool hot = (double)(mt() >> 11) * (1.0 / 9007199254740992.0) < f;
-            v = hot ? (uint32_t)(mt() % hot_rows) : hot_rows + (uint32_t)(mt() % cold_rows);
+            v = (hot && hot_rows) ? (uint32_t)(mt() % hot_rows) : hot_rows + (uint32_t)(mt() % cold_rows);
         }
         CK(hipMemcpy(d_i, ids.data(), n * 4, hipMemcpyHostToDevice));
         float best = 1e30f;
