@@ -325,6 +325,39 @@ def test_cli_survives_a_lost_launch(tmp_path):
     assert outs["healthy"] == outs["snapshot"] == outs["rerun"]
 
 
+def test_measurement_hooks_of_the_selftest_build(F):
+    """f2v_test_plan_gather (the launch plan of a minibatch replayed by a gather-only kernel) and f2v_test_xcd_times (per-XCD workgroup timing of the step kernel) are what
+    tools/plan_gather_probe.py and tools/xcd_balance_probe.py stand on: they run, time something, count every workgroup once -- and leave the next f2v_train bit-exact."""
+    import ctypes as C
+    from force2vec_amd import _lib
+    rowptr, colids = F.read_mtx(golden_graph_path("cora.mtx"))
+    T = _lib.selftest_lib()
+    eng = F.Engine(rowptr, colids, 128, selftest=True)
+    eng.srand(1)
+    eng.init_embeddings(0)
+    out = np.zeros(32, dtype=np.uint64)
+    _lib.check(T.f2v_test_xcd_times(eng._h, 1, None), T)
+    ids = np.array([1, 2, 3, 4, 5], dtype=np.uint32)
+    eng.minibatch_step(5, 0, 1024, ids, 5, 0.02)
+    eng.flush()
+    _lib.check(T.f2v_test_xcd_times(eng._h, 0, out.ctypes.data_as(C.POINTER(C.c_uint64))), T)
+    wgs = out[24:32].astype(np.int64)
+    assert wgs.sum() >= 1024 // 16 and (out[0:8][wgs > 0] >= out[8:16][wgs > 0]).all() and (out[16:24][wgs > 0] > 0).all()
+    us = C.c_double()
+    for mode in (0, 3, 3 | 4):
+        _lib.check(T.f2v_test_plan_gather(eng._h, 1024, 2048, mode, 2, C.byref(us)), T)
+        assert 0.5 < us.value < 1e5
+    assert T.f2v_test_plan_gather(eng._h, 5, 5, 0, 1, C.byref(us)) != 0      # an empty range is refused
+    # mode bit 1 wrote rows of the second matrix: a fresh start gives the oracle's bits again
+    eng.srand(1)
+    eng.init_embeddings(0)
+    eng.train(5, 2, 256)
+    X = eng.get_embeddings()
+    chunk = eng.get_param("hub_chunk")
+    eng.close()
+    assert np.array_equal(X, O.train(5, rowptr, colids, 128, 2, 256, order=O.ORDER_TREE, chunk=chunk))
+
+
 def test_cli_with_the_selftest_build_preloaded(tmp_path):
     """Round 3's failing invocation, kept: bin/Force2Vec (linked against libf2v.so) with LD_PRELOAD=libf2v_selftest.so ended in
     `Memory access fault by GPU ... on address 0x1000`.  Cause: both libraries exported every kernel's host-side handle variable
